@@ -1,0 +1,160 @@
+/* plonk_hip.h — C ABI of the MI355X (gfx950) implementation of the PLONK polynomial hot path.
+ *
+ * Every entry point replaces one generic Rust function of wu-s-john/PLONK (cited per
+ * declaration, paths relative to the reference tree).  The reference has no FFI of its own;
+ * a Rust caller binds these symbols from an `extern "C"` block and keeps its signatures.
+ *
+ * Conventions
+ *  - Field: BLS12-381 scalar field.  An element is 4 little-endian uint64_t limbs in Montgomery
+ *    form with R = 2^256 — byte-for-byte the memory of ark-ff 0.3 `Fp256<P>` (`x.0.0`).
+ *    Columns are contiguous arrays of elements (n * 4 uint64_t).
+ *  - sigma columns are arrays of uint64_t row indices (`PermutationTable<usize>`,
+ *    src/permutation_polynomial.rs:51-61).
+ *  - `sel[k]` / `sel_out[k]` are indexed by `ASTKind` declaration order
+ *    (Int, Bool, Add, Sub, Mult, Div, Eq, Not, If — src/ast.rs:56-66); NULL = column absent.
+ *  - Domains are the power-of-two multiplicative subgroups ark-poly's `GeneralEvaluationDomain`
+ *    builds (`Radix2EvaluationDomain`); only the size crosses the ABI.
+ *  - Return value: PLK_OK or a negative code; each code stands for one reference panic.
+ *  - Host entry points (`plk_*`) take caller-owned host memory, are synchronous and never keep a
+ *    pointer.  Device entry points (`plk_dev_*`) take device memory of the context's GPU and
+ *    enqueue on the given hipStream_t (passed as void*); data-dependent failures (zero
+ *    denominator, sigma out of range) are reported by plk_dev_status().
+ *  - One context per GPU; a context must not be used from two threads at once.
+ */
+#ifndef PLONK_HIP_H
+#define PLONK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct plk_ctx plk_ctx;
+
+enum {
+  PLK_OK = 0,
+  PLK_ERR_LENGTH = -1,           /* assert_eq!(evals.len(), domain.size()) — src/polynomial_utils.rs:22-26, :56-60 */
+  PLK_ERR_NOT_POW2 = -2,         /* domain size is not a power of two (Radix2EvaluationDomain only) */
+  PLK_ERR_TWO_ADICITY = -3,      /* log2(domain size) exceeds the field's two-adicity (32) */
+  PLK_ERR_ZERO_DENOMINATOR = -4, /* `denominator.inverse().unwrap()` — src/permutation_polynomial.rs:258 */
+  PLK_ERR_SIGMA_RANGE = -5,      /* slice index out of bounds — src/permutation_polynomial.rs:235-238 */
+  PLK_ERR_HIP = -6,              /* HIP runtime failure (see plk_last_error) */
+  PLK_ERR_ARG = -7,              /* NULL where a pointer is required, z_shift >= N, batch too large ... */
+  PLK_ERR_NOMEM = -8             /* device or host allocation failed */
+};
+
+#define PLK_NUM_WIRES 4
+#define PLK_NUM_SELECTORS 9
+#define PLK_MAX_BATCH 24
+#define PLK_INPUT_FIELD 0u  /* column of field elements */
+#define PLK_INPUT_U64 1u    /* column of uint64_t indices, converted with F::from(u64) on load */
+
+/* ---- context ---------------------------------------------------------------------------- */
+
+int plk_ctx_create(int device, plk_ctx** out);
+void plk_ctx_destroy(plk_ctx* ctx);
+const char* plk_strerror(int code);
+/* text of the last failure on this context ("" if none) */
+const char* plk_last_error(const plk_ctx* ctx);
+/* row reported by the last PLK_ERR_ZERO_DENOMINATOR / PLK_ERR_SIGMA_RANGE, or -1 */
+long long plk_last_error_row(const plk_ctx* ctx);
+/* field constants, 4 limbs each: modulus (plain integer), one (= R mod p), R^2 mod p */
+void plk_field_constants(uint64_t modulus[4], uint64_t one[4], uint64_t r2[4]);
+
+/* ---- host entry points: the reference's seven functions ---------------------------------- */
+
+/* evaluations_to_dense_polynomial — src/polynomial_utils.rs:18-33.
+ * Inverse DFT over the size-`domain_size` subgroup, natural order, 1/n included.
+ * Writes all `domain_size` coefficients (DensePolynomial::from_coefficients_vec would only
+ * drop trailing zero coefficients). PLK_ERR_LENGTH if evals_len != domain_size. */
+int plk_intt(plk_ctx* ctx, const uint64_t* evals, size_t evals_len, size_t domain_size, uint64_t* coeffs_out);
+
+/* build_and_convert — src/polynomial_utils.rs:47-62.  `builder` fills up to `capacity`
+ * elements and returns how many evaluations it produced (may exceed capacity to report an
+ * over-long vector); the count is checked against domain_size as at :56-60. */
+typedef size_t (*plk_builder_fn)(void* user, uint64_t* evals_out, size_t capacity);
+int plk_build_and_convert(plk_ctx* ctx, size_t domain_size, plk_builder_fn builder, void* user, uint64_t* coeffs_out);
+
+/* DensePolynomial::evaluate_over_domain_by_ref as called at src/execution_trace.rs:362-370 and
+ * src/permutation_polynomial.rs:323-334: zero-pad to domain_size, forward DFT. */
+int plk_ntt(plk_ctx* ctx, const uint64_t* coeffs, size_t n_coeffs, size_t domain_size, uint64_t* evals_out);
+
+/* gate_evaluation_table_to_gate_polynomial — src/execution_trace.rs:318-344. */
+int plk_gate_polys(plk_ctx* ctx, const uint64_t* const wires[PLK_NUM_WIRES], const uint64_t* const sel[PLK_NUM_SELECTORS],
+                   size_t n, size_t domain_size,
+                   uint64_t* const wires_out[PLK_NUM_WIRES], uint64_t* const sel_out[PLK_NUM_SELECTORS]);
+
+/* build_gate_constraint_evaluation_polynomial — src/execution_trace.rs:357-431.
+ * Coefficient vectors of n_coeffs elements each, evaluated on the size-N domain. */
+int plk_gate_constraints(plk_ctx* ctx, const uint64_t* const wire_coeffs[PLK_NUM_WIRES],
+                         const uint64_t* const sel_coeffs[PLK_NUM_SELECTORS], size_t n_coeffs, size_t N, uint64_t* out);
+
+/* build_grand_product_evaluation_polynomial — src/permutation_polynomial.rs:217-261.
+ * z_out receives n + 1 elements. */
+int plk_grand_product(plk_ctx* ctx, const uint64_t* const wires[PLK_NUM_WIRES], const uint64_t* const sigma[PLK_NUM_WIRES],
+                      size_t n, const uint64_t beta[4], const uint64_t gamma[4], uint64_t* z_out);
+
+/* build_permutation_polynomials — src/permutation_polynomial.rs:272-298.
+ * The reference interpolates the n+1 grand-product values on a size-n domain and therefore
+ * panics on its own length assert whenever n == domain_size; this entry point interpolates
+ * z[0..n) and returns z[n] through z_last_out (may be NULL). Requires n == domain_size. */
+int plk_perm_polys(plk_ctx* ctx, const uint64_t* const wires[PLK_NUM_WIRES], const uint64_t* const sigma[PLK_NUM_WIRES],
+                   size_t n, size_t domain_size, const uint64_t beta[4], const uint64_t gamma[4],
+                   uint64_t* const sigma_coeffs_out[PLK_NUM_WIRES], uint64_t* z_coeffs_out, uint64_t* z_last_out);
+
+/* build_permutation_constraint_evaluation_polynomial — src/permutation_polynomial.rs:312-376.
+ * z_shift = 1 reproduces the reference (`z_evals[(i + 1) % n]`, :347). */
+int plk_perm_constraints(plk_ctx* ctx, const uint64_t* z_coeffs, const uint64_t* const sigma_coeffs[PLK_NUM_WIRES],
+                         const uint64_t* const wire_coeffs[PLK_NUM_WIRES], size_t n_coeffs, size_t N,
+                         const uint64_t beta[4], const uint64_t gamma[4], size_t z_shift, uint64_t* out);
+
+/* Rounds 2+3 in one call, device-resident between the steps: the composition
+ * gate polys (:318) -> grand product (:217) -> sigma/Z interpolation (:272) ->
+ * gate constraints (:357) -> permutation constraints (:312), wires evaluated once.
+ * z_out: n+1 elements; gate_out, perm_out: N elements.  Any output may be NULL. */
+int plk_round23(plk_ctx* ctx, const uint64_t* const wires[PLK_NUM_WIRES], const uint64_t* const sel[PLK_NUM_SELECTORS],
+                const uint64_t* const sigma[PLK_NUM_WIRES], size_t n, size_t N,
+                const uint64_t beta[4], const uint64_t gamma[4], size_t z_shift,
+                uint64_t* z_out, uint64_t* gate_out, uint64_t* perm_out);
+
+/* ---- device entry points (same arithmetic, device pointers, asynchronous) ---------------- */
+
+/* `batch` transforms of size N in one set of launches.  in[b] holds n_in valid elements
+ * (zero-padded to N), of kind kinds[b] (PLK_INPUT_*; kinds == NULL means all field).
+ * inverse != 0: inverse DFT including 1/N.  out[b] may alias in[b]. */
+int plk_dev_ntt_batch(plk_ctx* ctx, void* stream, const uint64_t* const* in, const uint32_t* kinds, size_t batch,
+                      size_t n_in, size_t N, int inverse, uint64_t* const* out);
+
+int plk_dev_grand_product(plk_ctx* ctx, void* stream, const uint64_t* const wires[PLK_NUM_WIRES],
+                          const uint64_t* const sigma[PLK_NUM_WIRES], size_t n,
+                          const uint64_t beta[4], const uint64_t gamma[4], uint64_t* z_out);
+
+/* loop of src/execution_trace.rs:379-428 on columns already evaluated on the N-point domain */
+int plk_dev_gate_constraint_eval(plk_ctx* ctx, void* stream, const uint64_t* const wire_evals[PLK_NUM_WIRES],
+                                 const uint64_t* const sel_evals[PLK_NUM_SELECTORS], size_t N, uint64_t* out);
+
+/* loop of src/permutation_polynomial.rs:341-373 on columns already evaluated on the N-point domain */
+int plk_dev_perm_constraint_eval(plk_ctx* ctx, void* stream, const uint64_t* z_evals,
+                                 const uint64_t* const sigma_evals[PLK_NUM_WIRES],
+                                 const uint64_t* const wire_evals[PLK_NUM_WIRES], size_t N,
+                                 const uint64_t beta[4], const uint64_t gamma[4], size_t z_shift, uint64_t* out);
+
+int plk_dev_round23(plk_ctx* ctx, void* stream, const uint64_t* const wires[PLK_NUM_WIRES],
+                    const uint64_t* const sel[PLK_NUM_SELECTORS], const uint64_t* const sigma[PLK_NUM_WIRES],
+                    size_t n, size_t N, const uint64_t beta[4], const uint64_t gamma[4], size_t z_shift,
+                    uint64_t* z_out, uint64_t* gate_out, uint64_t* perm_out);
+
+/* Waits for `stream` and returns the deferred data-dependent status of the device calls
+ * enqueued since the last plk_dev_status (PLK_OK, PLK_ERR_ZERO_DENOMINATOR, PLK_ERR_SIGMA_RANGE). */
+int plk_dev_status(plk_ctx* ctx, void* stream);
+
+/* canonical integer limbs <-> Montgomery limbs, n elements, device pointers, out may alias in */
+int plk_dev_to_montgomery(plk_ctx* ctx, void* stream, const uint64_t* in, size_t n, uint64_t* out);
+int plk_dev_from_montgomery(plk_ctx* ctx, void* stream, const uint64_t* in, size_t n, uint64_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLONK_HIP_H */

@@ -1,0 +1,13 @@
+"""MI355X-native PLONK polynomial hot path (NTT/iNTT, grand product Z, constraint evaluation).
+
+The compute lives in libplonk_hip.so (hand-written HIP for gfx950, C ABI in include/plonk_hip.h);
+this package is the host-side mirror of the reference's Rust interface on top of it.
+"""
+from .api import (AST_KINDS, Context, GateEvaluationTable, GatePolynomials, GeneralEvaluationDomain, LengthMismatch,
+                  PermutationPolynomials, PermutationTable, PlonkError, Radix2EvaluationDomain, SigmaOutOfRange,
+                  ZeroDenominator, build_and_convert, build_gate_constraint_evaluation_polynomial,
+                  build_grand_product_evaluation_polynomial, build_permutation_constraint_evaluation_polynomial,
+                  build_permutation_polynomials, degree, evaluate_over_domain, evaluations_to_dense_polynomial,
+                  gate_evaluation_table_to_gate_polynomial, prove_round23)
+
+__all__ = [n for n in dir() if not n.startswith("_")]

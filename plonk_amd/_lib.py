@@ -1,0 +1,86 @@
+"""ctypes binding of libplonk_hip.so (the C ABI declared in include/plonk_hip.h).
+
+There is no CPU fallback: importing succeeds without the library so that host-side code
+and CPU tests can run, but any call that needs it raises `LibraryMissing`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libplonk_hip.so")
+
+PLK_OK = 0
+PLK_ERR_LENGTH = -1
+PLK_ERR_NOT_POW2 = -2
+PLK_ERR_TWO_ADICITY = -3
+PLK_ERR_ZERO_DENOMINATOR = -4
+PLK_ERR_SIGMA_RANGE = -5
+PLK_ERR_HIP = -6
+PLK_ERR_ARG = -7
+PLK_ERR_NOMEM = -8
+
+NUM_WIRES = 4
+NUM_SELECTORS = 9
+MAX_BATCH = 24
+INPUT_FIELD = 0
+INPUT_U64 = 1
+
+u64p = C.POINTER(C.c_uint64)
+u64pp = C.POINTER(u64p)
+u32p = C.POINTER(C.c_uint32)
+BUILDER_FN = C.CFUNCTYPE(C.c_size_t, C.c_void_p, u64p, C.c_size_t)
+
+#: every symbol include/plonk_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "plk_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "plk_ctx_destroy": (None, [C.c_void_p]),
+    "plk_strerror": (C.c_char_p, [C.c_int]),
+    "plk_last_error": (C.c_char_p, [C.c_void_p]),
+    "plk_last_error_row": (C.c_longlong, [C.c_void_p]),
+    "plk_field_constants": (None, [u64p, u64p, u64p]),
+    "plk_intt": (C.c_int, [C.c_void_p, u64p, C.c_size_t, C.c_size_t, u64p]),
+    "plk_build_and_convert": (C.c_int, [C.c_void_p, C.c_size_t, BUILDER_FN, C.c_void_p, u64p]),
+    "plk_ntt": (C.c_int, [C.c_void_p, u64p, C.c_size_t, C.c_size_t, u64p]),
+    "plk_gate_polys": (C.c_int, [C.c_void_p, u64pp, u64pp, C.c_size_t, C.c_size_t, u64pp, u64pp]),
+    "plk_gate_constraints": (C.c_int, [C.c_void_p, u64pp, u64pp, C.c_size_t, C.c_size_t, u64p]),
+    "plk_grand_product": (C.c_int, [C.c_void_p, u64pp, u64pp, C.c_size_t, u64p, u64p, u64p]),
+    "plk_perm_polys": (C.c_int, [C.c_void_p, u64pp, u64pp, C.c_size_t, C.c_size_t, u64p, u64p, u64pp, u64p, u64p]),
+    "plk_perm_constraints": (C.c_int, [C.c_void_p, u64p, u64pp, u64pp, C.c_size_t, C.c_size_t, u64p, u64p, C.c_size_t, u64p]),
+    "plk_round23": (C.c_int, [C.c_void_p, u64pp, u64pp, u64pp, C.c_size_t, C.c_size_t, u64p, u64p, C.c_size_t, u64p, u64p, u64p]),
+    "plk_dev_ntt_batch": (C.c_int, [C.c_void_p, C.c_void_p, u64pp, u32p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, u64pp]),
+    "plk_dev_grand_product": (C.c_int, [C.c_void_p, C.c_void_p, u64pp, u64pp, C.c_size_t, u64p, u64p, u64p]),
+    "plk_dev_gate_constraint_eval": (C.c_int, [C.c_void_p, C.c_void_p, u64pp, u64pp, C.c_size_t, u64p]),
+    "plk_dev_perm_constraint_eval": (C.c_int, [C.c_void_p, C.c_void_p, u64p, u64pp, u64pp, C.c_size_t, u64p, u64p, C.c_size_t, u64p]),
+    "plk_dev_round23": (C.c_int, [C.c_void_p, C.c_void_p, u64pp, u64pp, u64pp, C.c_size_t, C.c_size_t, u64p, u64p, C.c_size_t, u64p, u64p, u64p]),
+    "plk_dev_status": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "plk_dev_to_montgomery": (C.c_int, [C.c_void_p, C.c_void_p, u64p, C.c_size_t, u64p]),
+    "plk_dev_from_montgomery": (C.c_int, [C.c_void_p, C.c_void_p, u64p, C.c_size_t, u64p]),
+}
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load libplonk_hip.so and type every entry point.  Raises LibraryMissing if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LibraryMissing(
+            f"{LIB_PATH} not found: build it with `make -C plonk_amd/csrc` (or __graft_entry__.build()); "
+            "there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header and library disagree
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib

@@ -1,0 +1,764 @@
+// C ABI of the library (declared in include/plonk_hip.h): context, transform plans,
+// workspace, and the host- and device-pointer entry points built on the kernels in
+// ntt.cuh, grand_product.cuh and constraints.cuh.
+#include "../../include/plonk_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "constraints.cuh"
+#include "field.cuh"
+#include "grand_product.cuh"
+#include "ntt.cuh"
+
+using namespace plk;
+
+namespace {
+
+constexpr size_t ELEM = 32;  // bytes per field element
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+struct NttPlan {
+  int log_n = 0;
+  int npass = 1;
+  int log_r[3] = {0, 0, 0};
+  NttTables tab{};
+  DevBuf master, hi, hi_scaled, lo, scale;
+};
+
+}  // namespace
+
+struct plk_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;  // used by the host entry points
+  std::map<std::pair<int, int>, NttPlan> plans;  // (log_n, inverse)
+  std::map<std::string, DevBuf> ws;              // grow-only workspace slots
+  GpStatus* status_dev = nullptr;
+  GpStatus* status_host = nullptr;  // pinned
+  std::string last_error;
+  long long last_row = -1;
+};
+
+namespace {
+
+int fail(plk_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->last_error = msg;
+  return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                          \
+  do {                                                                                              \
+    hipError_t e_ = (expr);                                                                         \
+    if (e_ != hipSuccess)                                                                           \
+      return fail(ctx, e_ == hipErrorOutOfMemory ? PLK_ERR_NOMEM : PLK_ERR_HIP,                     \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                               \
+  } while (0)
+
+int log2_exact(size_t n) {
+  if (n == 0 || (n & (n - 1))) return -1;
+  int l = 0;
+  while ((size_t(1) << l) < n) ++l;
+  return l;
+}
+
+int check_domain(plk_ctx* ctx, size_t n, int* log_n) {
+  const int l = log2_exact(n);
+  if (l < 0) return fail(ctx, PLK_ERR_NOT_POW2, "domain size " + std::to_string(n) + " is not a power of two");
+  if (l > Field::TWO_ADICITY) return fail(ctx, PLK_ERR_TWO_ADICITY, "domain size exceeds the field's two-adicity");
+  *log_n = l;
+  return PLK_OK;
+}
+
+int ws_get(plk_ctx* ctx, const std::string& slot, size_t bytes, void** out) {
+  DevBuf& b = ctx->ws[slot];
+  if (b.cap < bytes) {
+    if (b.p) { HIP_TRY(ctx, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    const size_t want = std::max<size_t>(bytes, 256);
+    HIP_TRY(ctx, hipMalloc(&b.p, want));
+    b.cap = want;
+  }
+  *out = b.p;
+  return PLK_OK;
+}
+
+Fe fe_from_limbs64(const uint64_t x[4]) {
+  Fe r;
+  for (int i = 0; i < 4; ++i) { r.l[2 * i] = (uint32_t)x[i]; r.l[2 * i + 1] = (uint32_t)(x[i] >> 32); }
+  return r;
+}
+
+bool fe_is_canonical(const Fe& a) {  // a < p
+  for (int i = 7; i >= 0; --i) {
+    if (a.l[i] != Field::P[i]) return a.l[i] < Field::P[i];
+  }
+  return false;
+}
+
+// omega_N (Montgomery form) by squaring the two-adic root down, as ark-ff's get_root_of_unity
+Fe root_of_unity(int log_n) {
+  Fe canon;
+  for (int i = 0; i < 8; ++i) canon.l[i] = Field::ROOT[i];
+  Fe w = fe_mul(canon, fe_r2());
+  for (int i = 0; i < Field::TWO_ADICITY - log_n; ++i) w = fe_sqr(w);
+  return w;
+}
+
+int alloc_table(plk_ctx* ctx, DevBuf& buf, uint64_t count, const Fe& base, int shift, const Fe& mul, hipStream_t s) {
+  HIP_TRY(ctx, hipMalloc(&buf.p, count * ELEM));
+  buf.cap = count * ELEM;
+  const unsigned threads = 256;
+  const unsigned blocks = (unsigned)((count + threads - 1) / threads);
+  hipLaunchKernelGGL(ntt_table_kernel, dim3(blocks), dim3(threads), 0, s, (uint64_t*)buf.p, count, base, shift, mul);
+  HIP_TRY(ctx, hipGetLastError());
+  return PLK_OK;
+}
+
+int get_plan(plk_ctx* ctx, int log_n, bool inverse, hipStream_t s, NttPlan** out) {
+  auto key = std::make_pair(log_n, inverse ? 1 : 0);
+  auto it = ctx->plans.find(key);
+  if (it != ctx->plans.end()) { *out = &it->second; return PLK_OK; }
+  NttPlan plan;
+  plan.log_n = log_n;
+  plan.npass = log_n <= NTT_TILE_LOG ? 1 : (log_n <= 16 ? 2 : 3);
+  const int base = log_n / plan.npass, rem = log_n % plan.npass;
+  for (int p = 0; p < plan.npass; ++p) plan.log_r[p] = base + (p < rem ? 1 : 0);
+
+  Fe w = root_of_unity(log_n);
+  Fe wm = root_of_unity(NTT_MASTER_LOG);
+  if (inverse) { w = fe_inverse(w); wm = fe_inverse(wm); }
+  const Fe one = fe_one();
+  int rc;
+  if ((rc = alloc_table(ctx, plan.master, 1ull << (NTT_MASTER_LOG - 1), wm, 0, one, s))) return rc;
+  const int lo_bits = log_n / 2;
+  if ((rc = alloc_table(ctx, plan.lo, 1ull << lo_bits, w, 0, one, s))) return rc;
+  if ((rc = alloc_table(ctx, plan.hi, 1ull << (log_n - lo_bits), w, lo_bits, one, s))) return rc;
+  plan.tab.master = (const uint64_t*)plan.master.p;
+  plan.tab.tw_lo = (const uint64_t*)plan.lo.p;
+  plan.tab.tw_hi = (const uint64_t*)plan.hi.p;
+  plan.tab.tw_hi_scaled = plan.tab.tw_hi;
+  plan.tab.scale = nullptr;
+  plan.tab.lo_bits = lo_bits;
+  if (inverse) {
+    const Fe n_inv = fe_inverse(fe_from_u64(1ull << log_n));
+    if (plan.npass == 1) {
+      if ((rc = alloc_table(ctx, plan.scale, 1, one, 0, n_inv, s))) return rc;
+      plan.tab.scale = (const uint64_t*)plan.scale.p;
+    } else {
+      if ((rc = alloc_table(ctx, plan.hi_scaled, 1ull << (log_n - lo_bits), w, lo_bits, n_inv, s))) return rc;
+      plan.tab.tw_hi_scaled = (const uint64_t*)plan.hi_scaled.p;
+    }
+  }
+  // tables may be used from another stream than the one that built them
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  auto ins = ctx->plans.emplace(key, plan);
+  *out = &ins.first->second;
+  return PLK_OK;
+}
+
+// Enqueue `batch` (<= NTT_MAX_BATCH) transforms.
+int launch_ntt(plk_ctx* ctx, hipStream_t s, const uint64_t* const* in, const uint32_t* kinds, size_t batch,
+               size_t n_in, size_t N, bool inverse, uint64_t* const* out, const char* tmp_slot = "ntt_tmp") {
+  int log_n, rc;
+  if ((rc = check_domain(ctx, N, &log_n))) return rc;
+  if (n_in > N) return fail(ctx, PLK_ERR_LENGTH, "more input elements than domain points");
+  if (batch == 0) return PLK_OK;
+  if (batch > NTT_MAX_BATCH) return fail(ctx, PLK_ERR_ARG, "batch exceeds PLK_MAX_BATCH");
+  NttPlan* plan;
+  if ((rc = get_plan(ctx, log_n, inverse, s, &plan))) return rc;
+
+  NttBatch src{};
+  for (size_t b = 0; b < batch; ++b) {
+    if ((!in[b] && n_in) || !out[b]) return fail(ctx, PLK_ERR_ARG, "null column pointer");
+    src.in[b] = in[b];
+    src.kind[b] = kinds ? kinds[b] : (uint32_t)NTT_IN_FIELD;
+  }
+  uint64_t* tmp = nullptr;
+  if (plan->npass > 1) {
+    void* p;
+    if ((rc = ws_get(ctx, tmp_slot, batch * N * ELEM, &p))) return rc;
+    tmp = (uint64_t*)p;
+  }
+  const size_t lds_bytes = 2 * NTT_TILE * sizeof(uint4);
+  const int P = plan->npass;
+  // non-final passes
+  int log_inner = log_n;
+  for (int p = 0; p + 1 < P; ++p) {
+    const int lr = plan->log_r[p];
+    log_inner -= lr;
+    NttPassArgs a{};
+    a.tab = plan->tab;
+    a.n_in = n_in;
+    a.log_n = log_n;
+    a.log_r = lr;
+    a.log_inner = log_inner;
+    a.log_c = std::min(NTT_TILE_LOG - lr, log_inner);
+    a.first = p == 0;
+    a.use_scaled = p == 0;
+    for (size_t b = 0; b < batch; ++b) {
+      a.batch.in[b] = p == 0 ? src.in[b] : tmp + b * N * 4;
+      a.batch.kind[b] = src.kind[b];
+      a.batch.out[b] = tmp + b * N * 4;
+    }
+    const unsigned tiles = 1u << (log_n - lr - a.log_c);
+    hipLaunchKernelGGL(ntt_pass_kernel, dim3(tiles, (unsigned)batch), dim3(NTT_THREADS), lds_bytes, s, a);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  {
+    NttFinalArgs a{};
+    a.tab = plan->tab;
+    a.n_in = n_in;
+    a.log_n = log_n;
+    a.log_r = plan->log_r[P - 1];
+    a.log_r1 = P >= 2 ? plan->log_r[0] : 0;
+    a.log_r2 = P >= 3 ? plan->log_r[1] : 0;
+    a.log_c = std::min(NTT_TILE_LOG - a.log_r, a.log_r1);
+    a.first = P == 1;
+    for (size_t b = 0; b < batch; ++b) {
+      a.batch.in[b] = P == 1 ? src.in[b] : tmp + b * N * 4;
+      a.batch.kind[b] = src.kind[b];
+      a.batch.out[b] = out[b];
+    }
+    const unsigned tiles = 1u << (log_n - a.log_r - a.log_c);
+    hipLaunchKernelGGL(ntt_final_kernel, dim3(tiles, (unsigned)batch), dim3(NTT_THREADS), lds_bytes, s, a);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  return PLK_OK;
+}
+
+int status_reset(plk_ctx* ctx, hipStream_t s) {
+  HIP_TRY(ctx, hipMemsetAsync(ctx->status_dev, 0xff, sizeof(GpStatus), s));
+  return PLK_OK;
+}
+
+int launch_grand_product(plk_ctx* ctx, hipStream_t s, const uint64_t* const wires[4], const uint64_t* const sigma[4],
+                         size_t n, const uint64_t beta_[4], const uint64_t gamma_[4], uint64_t* z_out) {
+  if (!z_out || !beta_ || !gamma_) return fail(ctx, PLK_ERR_ARG, "null pointer");
+  const Fe beta = fe_from_limbs64(beta_), gamma = fe_from_limbs64(gamma_);
+  if (!fe_is_canonical(beta) || !fe_is_canonical(gamma)) return fail(ctx, PLK_ERR_ARG, "beta/gamma not reduced mod p");
+  const Fe one = fe_one();
+  if (n == 0) {  // z = [1]
+    HIP_TRY(ctx, hipMemcpyAsync(z_out, &one, ELEM, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return PLK_OK;
+  }
+  GpCols cols{};
+  for (int k = 0; k < 4; ++k) {
+    if (!wires[k] || !sigma[k]) return fail(ctx, PLK_ERR_ARG, "null column pointer");
+    cols.v[k] = wires[k];
+    cols.sigma[k] = sigma[k];
+  }
+  const size_t nb = (n + GP_BLOCK_ROWS - 1) / GP_BLOCK_ROWS;
+  void *num, *den, *bn, *bd;
+  int rc;
+  if ((rc = ws_get(ctx, "gp_num", n * ELEM, &num))) return rc;
+  if ((rc = ws_get(ctx, "gp_den", n * ELEM, &den))) return rc;
+  if ((rc = ws_get(ctx, "gp_bnum", nb * ELEM, &bn))) return rc;
+  if ((rc = ws_get(ctx, "gp_bden", nb * ELEM, &bd))) return rc;
+  const Fe beta_r2 = fe_mul(beta, fe_r2());
+  hipLaunchKernelGGL(gp_terms_kernel, dim3((unsigned)nb), dim3(GP_THREADS), 0, s, cols, (uint64_t)n, beta, gamma, beta_r2,
+                     (uint64_t*)num, (uint64_t*)den, (uint64_t*)bn, (uint64_t*)bd, ctx->status_dev);
+  HIP_TRY(ctx, hipGetLastError());
+  hipLaunchKernelGGL(gp_block_scan_kernel, dim3(1), dim3(GP_SCAN_THREADS), 0, s, (uint64_t*)bn, (uint64_t*)bd, (uint32_t)nb);
+  HIP_TRY(ctx, hipGetLastError());
+  hipLaunchKernelGGL(gp_finish_kernel, dim3((unsigned)nb), dim3(GP_THREADS), 0, s, (const uint64_t*)num, (const uint64_t*)den,
+                     (uint64_t)n, (const uint64_t*)bn, (const uint64_t*)bd, z_out);
+  HIP_TRY(ctx, hipGetLastError());
+  return PLK_OK;
+}
+
+int launch_gate_eval(plk_ctx* ctx, hipStream_t s, const uint64_t* const w[4], const uint64_t* const sel[9], size_t N,
+                     uint64_t* out) {
+  if (!out) return fail(ctx, PLK_ERR_ARG, "null output");
+  if (N == 0) return PLK_OK;
+  GateCols cols{};
+  for (int k = 0; k < 4; ++k) { if (!w[k]) return fail(ctx, PLK_ERR_ARG, "null wire column"); cols.w[k] = w[k]; }
+  for (int k = 0; k < 9; ++k) cols.s[k] = sel ? sel[k] : nullptr;
+  const unsigned blocks = (unsigned)((N + EW_THREADS - 1) / EW_THREADS);
+  hipLaunchKernelGGL(gate_constraint_kernel, dim3(blocks), dim3(EW_THREADS), 0, s, cols, (uint64_t)N, out);
+  HIP_TRY(ctx, hipGetLastError());
+  return PLK_OK;
+}
+
+int launch_perm_eval(plk_ctx* ctx, hipStream_t s, const uint64_t* z, const uint64_t* const sg[4], const uint64_t* const w[4],
+                     size_t N, const uint64_t beta_[4], const uint64_t gamma_[4], size_t z_shift, uint64_t* out) {
+  if (!out || !z || !beta_ || !gamma_) return fail(ctx, PLK_ERR_ARG, "null pointer");
+  if (N == 0) return PLK_OK;
+  if (z_shift >= N) z_shift %= N;
+  const Fe beta = fe_from_limbs64(beta_), gamma = fe_from_limbs64(gamma_);
+  if (!fe_is_canonical(beta) || !fe_is_canonical(gamma)) return fail(ctx, PLK_ERR_ARG, "beta/gamma not reduced mod p");
+  PermCols cols{};
+  cols.z = z;
+  for (int k = 0; k < 4; ++k) {
+    if (!w[k] || !sg[k]) return fail(ctx, PLK_ERR_ARG, "null column pointer");
+    cols.w[k] = w[k];
+    cols.s[k] = sg[k];
+  }
+  const Fe beta_r2 = fe_mul(beta, fe_r2());
+  const unsigned blocks = (unsigned)((N + EW_THREADS - 1) / EW_THREADS);
+  hipLaunchKernelGGL(perm_constraint_kernel, dim3(blocks), dim3(EW_THREADS), 0, s, cols, (uint64_t)N, beta, gamma, beta_r2,
+                     (uint64_t)z_shift, out);
+  HIP_TRY(ctx, hipGetLastError());
+  return PLK_OK;
+}
+
+// Rounds 2+3 on device columns.  Workspace: 18 coefficient vectors (n) and 18 evaluation
+// vectors (N).  Column order inside the workspace: wires 0-3, selectors 4-12, sigma 13-16, z 17.
+int launch_round23(plk_ctx* ctx, hipStream_t s, const uint64_t* const wires[4], const uint64_t* const sel[9],
+                   const uint64_t* const sigma[4], size_t n, size_t N, const uint64_t beta[4], const uint64_t gamma[4],
+                   size_t z_shift, uint64_t* z_out, uint64_t* gate_out, uint64_t* perm_out) {
+  int rc, log_n, log_N;
+  if ((rc = check_domain(ctx, n, &log_n))) return rc;
+  if ((rc = check_domain(ctx, N, &log_N))) return rc;
+  if (n > N) return fail(ctx, PLK_ERR_LENGTH, "evaluation domain smaller than the trace");
+  constexpr int NCOL = 18;
+  void *coef_p, *eval_p, *z_p;
+  if ((rc = ws_get(ctx, "r23_coef", (size_t)NCOL * n * ELEM, &coef_p))) return rc;
+  if ((rc = ws_get(ctx, "r23_eval", (size_t)NCOL * N * ELEM, &eval_p))) return rc;
+  if ((rc = ws_get(ctx, "r23_z", (n + 1) * ELEM, &z_p))) return rc;
+  uint64_t* coef = (uint64_t*)coef_p;
+  uint64_t* eval = (uint64_t*)eval_p;
+  uint64_t* z = z_out ? z_out : (uint64_t*)z_p;
+
+  if ((rc = launch_grand_product(ctx, s, wires, sigma, n, beta, gamma, z))) return rc;
+
+  // interpolation of every column present (rows 3 and 6 of the path): one batched inverse transform
+  const uint64_t* in[NCOL]; uint64_t* out[NCOL]; uint32_t kinds[NCOL]; int col_of[NCOL]; size_t m = 0;
+  auto col_coef = [&](int c) { return coef + (size_t)c * n * 4; };
+  auto col_eval = [&](int c) { return eval + (size_t)c * N * 4; };
+  for (int k = 0; k < 4; ++k) { in[m] = wires[k]; kinds[m] = NTT_IN_FIELD; col_of[m] = k; ++m; }
+  for (int k = 0; k < 9; ++k) if (sel && sel[k]) { in[m] = sel[k]; kinds[m] = NTT_IN_FIELD; col_of[m] = 4 + k; ++m; }
+  for (int k = 0; k < 4; ++k) { in[m] = sigma[k]; kinds[m] = NTT_IN_U64; col_of[m] = 13 + k; ++m; }
+  in[m] = z; kinds[m] = NTT_IN_FIELD; col_of[m] = 17; ++m;
+  for (size_t b = 0; b < m; ++b) out[b] = col_coef(col_of[b]);
+  if ((rc = launch_ntt(ctx, s, in, kinds, m, n, n, true, out))) return rc;
+
+  // evaluation of every coefficient vector on the N-point domain (wires once, shared by both checks)
+  for (size_t b = 0; b < m; ++b) { in[b] = col_coef(col_of[b]); out[b] = col_eval(col_of[b]); }
+  if ((rc = launch_ntt(ctx, s, in, nullptr, m, n, N, false, out))) return rc;
+
+  const uint64_t* w_ev[4] = {col_eval(0), col_eval(1), col_eval(2), col_eval(3)};
+  const uint64_t* s_ev[9];
+  for (int k = 0; k < 9; ++k) s_ev[k] = (sel && sel[k]) ? col_eval(4 + k) : nullptr;
+  const uint64_t* g_ev[4] = {col_eval(13), col_eval(14), col_eval(15), col_eval(16)};
+  if (gate_out && (rc = launch_gate_eval(ctx, s, w_ev, s_ev, N, gate_out))) return rc;
+  if (perm_out && (rc = launch_perm_eval(ctx, s, col_eval(17), g_ev, w_ev, N, beta, gamma, z_shift, perm_out))) return rc;
+  return PLK_OK;
+}
+
+int fetch_status(plk_ctx* ctx, hipStream_t s) {
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->status_host, ctx->status_dev, sizeof(GpStatus), hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  const GpStatus st = *ctx->status_host;
+  int rc = PLK_OK;
+  // the reference's loop reaches the slice index of row j before that row's inversion
+  if (st.bad_sigma_row != ~0ull && st.bad_sigma_row <= st.zero_den_row) {
+    ctx->last_row = (long long)st.bad_sigma_row;
+    rc = fail(ctx, PLK_ERR_SIGMA_RANGE, "sigma index out of range at row " + std::to_string(st.bad_sigma_row));
+  } else if (st.zero_den_row != ~0ull) {
+    ctx->last_row = (long long)st.zero_den_row;
+    rc = fail(ctx, PLK_ERR_ZERO_DENOMINATOR, "zero denominator at row " + std::to_string(st.zero_den_row));
+  }
+  if (rc != PLK_OK) { int r2 = status_reset(ctx, s); if (r2) return r2; }
+  return rc;
+}
+
+// ---- host staging helpers
+
+struct Staged {
+  plk_ctx* ctx;
+  std::vector<void*> bufs;
+  explicit Staged(plk_ctx* c) : ctx(c) {}
+  ~Staged() { for (void* p : bufs) (void)hipFree(p); }
+  int alloc(size_t bytes, void** out) {
+    void* p = nullptr;
+    HIP_TRY(ctx, hipMalloc(&p, std::max<size_t>(bytes, 32)));
+    bufs.push_back(p);
+    *out = p;
+    return PLK_OK;
+  }
+  int upload(const void* host, size_t bytes, void** out) {
+    int rc = alloc(bytes, out);
+    if (rc) return rc;
+    if (bytes) HIP_TRY(ctx, hipMemcpyAsync(*out, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return PLK_OK;
+  }
+};
+
+int use_device(plk_ctx* ctx) {
+  if (!ctx) return PLK_ERR_ARG;
+  ctx->last_error.clear();
+  ctx->last_row = -1;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  return PLK_OK;
+}
+
+}  // namespace
+
+// ============================================================================ extern "C"
+
+extern "C" {
+
+int plk_ctx_create(int device, plk_ctx** out) {
+  if (!out) return PLK_ERR_ARG;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return PLK_ERR_HIP;
+  plk_ctx* ctx = new (std::nothrow) plk_ctx();
+  if (!ctx) return PLK_ERR_NOMEM;
+  ctx->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipMalloc((void**)&ctx->status_dev, sizeof(GpStatus)) != hipSuccess ||
+      hipHostMalloc((void**)&ctx->status_host, sizeof(GpStatus)) != hipSuccess ||
+      hipMemset(ctx->status_dev, 0xff, sizeof(GpStatus)) != hipSuccess) {
+    plk_ctx_destroy(ctx);
+    return PLK_ERR_HIP;
+  }
+  *out = ctx;
+  return PLK_OK;
+}
+
+void plk_ctx_destroy(plk_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  (void)hipDeviceSynchronize();
+  for (auto& kv : ctx->plans) {
+    NttPlan& p = kv.second;
+    for (DevBuf* b : {&p.master, &p.hi, &p.hi_scaled, &p.lo, &p.scale}) if (b->p) (void)hipFree(b->p);
+  }
+  for (auto& kv : ctx->ws) if (kv.second.p) (void)hipFree(kv.second.p);
+  if (ctx->status_dev) (void)hipFree(ctx->status_dev);
+  if (ctx->status_host) (void)hipHostFree(ctx->status_host);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* plk_strerror(int code) {
+  switch (code) {
+    case PLK_OK: return "ok";
+    case PLK_ERR_LENGTH: return "Evaluation length must match the domain size";
+    case PLK_ERR_NOT_POW2: return "domain size is not a power of two";
+    case PLK_ERR_TWO_ADICITY: return "domain size exceeds the field's two-adicity";
+    case PLK_ERR_ZERO_DENOMINATOR: return "zero denominator in the grand product (inverse of zero)";
+    case PLK_ERR_SIGMA_RANGE: return "sigma index out of range";
+    case PLK_ERR_HIP: return "HIP runtime error";
+    case PLK_ERR_ARG: return "invalid argument";
+    case PLK_ERR_NOMEM: return "out of memory";
+    default: return "unknown error";
+  }
+}
+
+const char* plk_last_error(const plk_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+long long plk_last_error_row(const plk_ctx* ctx) { return ctx ? ctx->last_row : -1; }
+
+void plk_field_constants(uint64_t modulus[4], uint64_t one[4], uint64_t r2[4]) {
+  for (int i = 0; i < 4; ++i) {
+    if (modulus) modulus[i] = (uint64_t)Field::P[2 * i] | ((uint64_t)Field::P[2 * i + 1] << 32);
+    if (one) one[i] = (uint64_t)Field::ONE[2 * i] | ((uint64_t)Field::ONE[2 * i + 1] << 32);
+    if (r2) r2[i] = (uint64_t)Field::R2[2 * i] | ((uint64_t)Field::R2[2 * i + 1] << 32);
+  }
+}
+
+// ---------------------------------------------------------------------------- device API
+
+int plk_dev_ntt_batch(plk_ctx* ctx, void* stream, const uint64_t* const* in, const uint32_t* kinds, size_t batch,
+                      size_t n_in, size_t N, int inverse, uint64_t* const* out) {
+  int rc = use_device(ctx);
+  if (rc) return rc;
+  if (!in || !out) return fail(ctx, PLK_ERR_ARG, "null pointer table");
+  for (size_t done = 0; done < batch; done += NTT_MAX_BATCH) {
+    const size_t m = std::min<size_t>(NTT_MAX_BATCH, batch - done);
+    if ((rc = launch_ntt(ctx, (hipStream_t)stream, in + done, kinds ? kinds + done : nullptr, m, n_in, N, inverse != 0, out + done)))
+      return rc;
+  }
+  return PLK_OK;
+}
+
+int plk_dev_grand_product(plk_ctx* ctx, void* stream, const uint64_t* const wires[4], const uint64_t* const sigma[4], size_t n,
+                          const uint64_t beta[4], const uint64_t gamma[4], uint64_t* z_out) {
+  int rc = use_device(ctx);
+  if (rc) return rc;
+  if (!wires || !sigma) return fail(ctx, PLK_ERR_ARG, "null pointer table");
+  return launch_grand_product(ctx, (hipStream_t)stream, wires, sigma, n, beta, gamma, z_out);
+}
+
+int plk_dev_gate_constraint_eval(plk_ctx* ctx, void* stream, const uint64_t* const wire_evals[4],
+                                 const uint64_t* const sel_evals[9], size_t N, uint64_t* out) {
+  int rc = use_device(ctx);
+  if (rc) return rc;
+  if (!wire_evals) return fail(ctx, PLK_ERR_ARG, "null pointer table");
+  return launch_gate_eval(ctx, (hipStream_t)stream, wire_evals, sel_evals, N, out);
+}
+
+int plk_dev_perm_constraint_eval(plk_ctx* ctx, void* stream, const uint64_t* z_evals, const uint64_t* const sigma_evals[4],
+                                 const uint64_t* const wire_evals[4], size_t N, const uint64_t beta[4],
+                                 const uint64_t gamma[4], size_t z_shift, uint64_t* out) {
+  int rc = use_device(ctx);
+  if (rc) return rc;
+  if (!sigma_evals || !wire_evals) return fail(ctx, PLK_ERR_ARG, "null pointer table");
+  return launch_perm_eval(ctx, (hipStream_t)stream, z_evals, sigma_evals, wire_evals, N, beta, gamma, z_shift, out);
+}
+
+int plk_dev_round23(plk_ctx* ctx, void* stream, const uint64_t* const wires[4], const uint64_t* const sel[9],
+                    const uint64_t* const sigma[4], size_t n, size_t N, const uint64_t beta[4], const uint64_t gamma[4],
+                    size_t z_shift, uint64_t* z_out, uint64_t* gate_out, uint64_t* perm_out) {
+  int rc = use_device(ctx);
+  if (rc) return rc;
+  if (!wires || !sigma) return fail(ctx, PLK_ERR_ARG, "null pointer table");
+  return launch_round23(ctx, (hipStream_t)stream, wires, sel, sigma, n, N, beta, gamma, z_shift, z_out, gate_out, perm_out);
+}
+
+int plk_dev_status(plk_ctx* ctx, void* stream) {
+  int rc = use_device(ctx);
+  if (rc) return rc;
+  return fetch_status(ctx, (hipStream_t)stream);
+}
+
+int plk_dev_to_montgomery(plk_ctx* ctx, void* stream, const uint64_t* in, size_t n, uint64_t* out) {
+  int rc = use_device(ctx);
+  if (rc) return rc;
+  if (n == 0) return PLK_OK;
+  if (!in || !out) return fail(ctx, PLK_ERR_ARG, "null pointer");
+  hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((n + EW_THREADS - 1) / EW_THREADS)), dim3(EW_THREADS), 0,
+                     (hipStream_t)stream, in, (uint64_t)n, fe_r2(), out);
+  HIP_TRY(ctx, hipGetLastError());
+  return PLK_OK;
+}
+
+int plk_dev_from_montgomery(plk_ctx* ctx, void* stream, const uint64_t* in, size_t n, uint64_t* out) {
+  int rc = use_device(ctx);
+  if (rc) return rc;
+  if (n == 0) return PLK_OK;
+  if (!in || !out) return fail(ctx, PLK_ERR_ARG, "null pointer");
+  Fe raw_one = fe_zero();
+  raw_one.l[0] = 1;
+  hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((n + EW_THREADS - 1) / EW_THREADS)), dim3(EW_THREADS), 0,
+                     (hipStream_t)stream, in, (uint64_t)n, raw_one, out);
+  HIP_TRY(ctx, hipGetLastError());
+  return PLK_OK;
+}
+
+// ---------------------------------------------------------------------------- host API
+
+int plk_intt(plk_ctx* ctx, const uint64_t* evals, size_t evals_len, size_t domain_size, uint64_t* coeffs_out) {
+  int rc = use_device(ctx), log_n;
+  if (rc) return rc;
+  if ((rc = check_domain(ctx, domain_size, &log_n))) return rc;
+  if (evals_len != domain_size) return fail(ctx, PLK_ERR_LENGTH, plk_strerror(PLK_ERR_LENGTH));
+  if (!evals || !coeffs_out) return fail(ctx, PLK_ERR_ARG, "null pointer");
+  Staged st(ctx);
+  void* d;
+  if ((rc = st.upload(evals, domain_size * ELEM, &d))) return rc;
+  const uint64_t* in[1] = {(const uint64_t*)d};
+  uint64_t* out[1] = {(uint64_t*)d};
+  if ((rc = launch_ntt(ctx, ctx->stream, in, nullptr, 1, domain_size, domain_size, true, out))) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(coeffs_out, d, domain_size * ELEM, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return PLK_OK;
+}
+
+int plk_build_and_convert(plk_ctx* ctx, size_t domain_size, plk_builder_fn builder, void* user, uint64_t* coeffs_out) {
+  if (!ctx) return PLK_ERR_ARG;
+  if (!builder || !coeffs_out) return fail(ctx, PLK_ERR_ARG, "null pointer");
+  std::vector<uint64_t> evals(domain_size * 4 + 4);
+  const size_t produced = builder(user, evals.data(), domain_size);
+  if (produced != domain_size) return fail(ctx, PLK_ERR_LENGTH, "Domain size and builder evaluations length should match");
+  return plk_intt(ctx, evals.data(), produced, domain_size, coeffs_out);
+}
+
+int plk_ntt(plk_ctx* ctx, const uint64_t* coeffs, size_t n_coeffs, size_t domain_size, uint64_t* evals_out) {
+  int rc = use_device(ctx), log_n;
+  if (rc) return rc;
+  if ((rc = check_domain(ctx, domain_size, &log_n))) return rc;
+  if (n_coeffs > domain_size) return fail(ctx, PLK_ERR_LENGTH, "more coefficients than domain points");
+  if ((!coeffs && n_coeffs) || !evals_out) return fail(ctx, PLK_ERR_ARG, "null pointer");
+  Staged st(ctx);
+  void *d_in, *d_out;
+  if ((rc = st.upload(coeffs, n_coeffs * ELEM, &d_in))) return rc;
+  if ((rc = st.alloc(domain_size * ELEM, &d_out))) return rc;
+  const uint64_t* in[1] = {(const uint64_t*)d_in};
+  uint64_t* out[1] = {(uint64_t*)d_out};
+  if ((rc = launch_ntt(ctx, ctx->stream, in, nullptr, 1, n_coeffs, domain_size, false, out))) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(evals_out, d_out, domain_size * ELEM, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return PLK_OK;
+}
+
+int plk_gate_polys(plk_ctx* ctx, const uint64_t* const wires[4], const uint64_t* const sel[9], size_t n, size_t domain_size,
+                   uint64_t* const wires_out[4], uint64_t* const sel_out[9]) {
+  int rc = use_device(ctx), log_n;
+  if (rc) return rc;
+  if ((rc = check_domain(ctx, domain_size, &log_n))) return rc;
+  if (n != domain_size) return fail(ctx, PLK_ERR_LENGTH, plk_strerror(PLK_ERR_LENGTH));
+  if (!wires || !wires_out) return fail(ctx, PLK_ERR_ARG, "null pointer table");
+  Staged st(ctx);
+  const uint64_t* in[13]; uint64_t* out[13]; uint64_t* host_out[13]; size_t m = 0;
+  for (int k = 0; k < 4; ++k) {
+    if (!wires[k] || !wires_out[k]) return fail(ctx, PLK_ERR_ARG, "null wire column");
+    void* d; if ((rc = st.upload(wires[k], n * ELEM, &d))) return rc;
+    in[m] = (const uint64_t*)d; out[m] = (uint64_t*)d; host_out[m] = wires_out[k]; ++m;
+  }
+  for (int k = 0; k < 9; ++k) {
+    if (!sel || !sel[k]) continue;
+    if (!sel_out || !sel_out[k]) return fail(ctx, PLK_ERR_ARG, "selector present but no output column");
+    void* d; if ((rc = st.upload(sel[k], n * ELEM, &d))) return rc;
+    in[m] = (const uint64_t*)d; out[m] = (uint64_t*)d; host_out[m] = sel_out[k]; ++m;
+  }
+  if ((rc = launch_ntt(ctx, ctx->stream, in, nullptr, m, n, domain_size, true, out))) return rc;
+  for (size_t b = 0; b < m; ++b) HIP_TRY(ctx, hipMemcpyAsync(host_out[b], out[b], n * ELEM, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return PLK_OK;
+}
+
+int plk_gate_constraints(plk_ctx* ctx, const uint64_t* const wire_coeffs[4], const uint64_t* const sel_coeffs[9], size_t n_coeffs,
+                         size_t N, uint64_t* out_host) {
+  int rc = use_device(ctx), log_n;
+  if (rc) return rc;
+  if ((rc = check_domain(ctx, N, &log_n))) return rc;
+  if (n_coeffs > N) return fail(ctx, PLK_ERR_LENGTH, "more coefficients than domain points");
+  if (!wire_coeffs || !out_host) return fail(ctx, PLK_ERR_ARG, "null pointer");
+  Staged st(ctx);
+  const uint64_t* in[13]; uint64_t* ev[13]; int col[13]; size_t m = 0;
+  for (int k = 0; k < 4; ++k) {
+    if (!wire_coeffs[k] && n_coeffs) return fail(ctx, PLK_ERR_ARG, "null wire column");
+    void *d, *e; if ((rc = st.upload(wire_coeffs[k], n_coeffs * ELEM, &d))) return rc; if ((rc = st.alloc(N * ELEM, &e))) return rc;
+    in[m] = (const uint64_t*)d; ev[m] = (uint64_t*)e; col[m] = k; ++m;
+  }
+  for (int k = 0; k < 9; ++k) {
+    if (!sel_coeffs || !sel_coeffs[k]) continue;
+    void *d, *e; if ((rc = st.upload(sel_coeffs[k], n_coeffs * ELEM, &d))) return rc; if ((rc = st.alloc(N * ELEM, &e))) return rc;
+    in[m] = (const uint64_t*)d; ev[m] = (uint64_t*)e; col[m] = 4 + k; ++m;
+  }
+  if ((rc = launch_ntt(ctx, ctx->stream, in, nullptr, m, n_coeffs, N, false, ev))) return rc;
+  const uint64_t* w[4]; const uint64_t* s[9] = {nullptr};
+  for (size_t b = 0; b < m; ++b) { if (col[b] < 4) w[col[b]] = ev[b]; else s[col[b] - 4] = ev[b]; }
+  void* d_out; if ((rc = st.alloc(N * ELEM, &d_out))) return rc;
+  if ((rc = launch_gate_eval(ctx, ctx->stream, w, s, N, (uint64_t*)d_out))) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(out_host, d_out, N * ELEM, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return PLK_OK;
+}
+
+int plk_grand_product(plk_ctx* ctx, const uint64_t* const wires[4], const uint64_t* const sigma[4], size_t n,
+                      const uint64_t beta[4], const uint64_t gamma[4], uint64_t* z_out) {
+  int rc = use_device(ctx);
+  if (rc) return rc;
+  if (!wires || !sigma || !z_out) return fail(ctx, PLK_ERR_ARG, "null pointer");
+  Staged st(ctx);
+  const uint64_t* w[4]; const uint64_t* sg[4];
+  for (int k = 0; k < 4; ++k) {
+    if (n && (!wires[k] || !sigma[k])) return fail(ctx, PLK_ERR_ARG, "null column pointer");
+    void *d, *e; if ((rc = st.upload(wires[k], n * ELEM, &d))) return rc; if ((rc = st.upload(sigma[k], n * 8, &e))) return rc;
+    w[k] = (const uint64_t*)d; sg[k] = (const uint64_t*)e;
+  }
+  void* dz; if ((rc = st.alloc((n + 1) * ELEM, &dz))) return rc;
+  if ((rc = launch_grand_product(ctx, ctx->stream, w, sg, n, beta, gamma, (uint64_t*)dz))) return rc;
+  if ((rc = fetch_status(ctx, ctx->stream))) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(z_out, dz, (n + 1) * ELEM, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return PLK_OK;
+}
+
+int plk_perm_polys(plk_ctx* ctx, const uint64_t* const wires[4], const uint64_t* const sigma[4], size_t n, size_t domain_size,
+                   const uint64_t beta[4], const uint64_t gamma[4], uint64_t* const sigma_coeffs_out[4], uint64_t* z_coeffs_out,
+                   uint64_t* z_last_out) {
+  int rc = use_device(ctx), log_n;
+  if (rc) return rc;
+  if ((rc = check_domain(ctx, domain_size, &log_n))) return rc;
+  if (n != domain_size) return fail(ctx, PLK_ERR_LENGTH, plk_strerror(PLK_ERR_LENGTH));
+  if (!wires || !sigma || !sigma_coeffs_out || !z_coeffs_out) return fail(ctx, PLK_ERR_ARG, "null pointer");
+  Staged st(ctx);
+  const uint64_t* w[4]; const uint64_t* sg[4];
+  for (int k = 0; k < 4; ++k) {
+    if (!wires[k] || !sigma[k] || !sigma_coeffs_out[k]) return fail(ctx, PLK_ERR_ARG, "null column pointer");
+    void *d, *e; if ((rc = st.upload(wires[k], n * ELEM, &d))) return rc; if ((rc = st.upload(sigma[k], n * 8, &e))) return rc;
+    w[k] = (const uint64_t*)d; sg[k] = (const uint64_t*)e;
+  }
+  void* dz; if ((rc = st.alloc((n + 1) * ELEM, &dz))) return rc;
+  if ((rc = launch_grand_product(ctx, ctx->stream, w, sg, n, beta, gamma, (uint64_t*)dz))) return rc;
+  if ((rc = fetch_status(ctx, ctx->stream))) return rc;
+  if (z_last_out) HIP_TRY(ctx, hipMemcpyAsync(z_last_out, (uint64_t*)dz + 4 * n, ELEM, hipMemcpyDeviceToHost, ctx->stream));
+  const uint64_t* in[5]; uint64_t* out[5]; uint32_t kinds[5];
+  for (int k = 0; k < 4; ++k) {
+    void* c; if ((rc = st.alloc(n * ELEM, &c))) return rc;
+    in[k] = sg[k]; kinds[k] = NTT_IN_U64; out[k] = (uint64_t*)c;
+  }
+  in[4] = (const uint64_t*)dz; kinds[4] = NTT_IN_FIELD; out[4] = (uint64_t*)dz;
+  if ((rc = launch_ntt(ctx, ctx->stream, in, kinds, 5, n, domain_size, true, out))) return rc;
+  for (int k = 0; k < 4; ++k) HIP_TRY(ctx, hipMemcpyAsync(sigma_coeffs_out[k], out[k], n * ELEM, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(z_coeffs_out, dz, n * ELEM, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return PLK_OK;
+}
+
+int plk_perm_constraints(plk_ctx* ctx, const uint64_t* z_coeffs, const uint64_t* const sigma_coeffs[4],
+                         const uint64_t* const wire_coeffs[4], size_t n_coeffs, size_t N, const uint64_t beta[4],
+                         const uint64_t gamma[4], size_t z_shift, uint64_t* out_host) {
+  int rc = use_device(ctx), log_n;
+  if (rc) return rc;
+  if ((rc = check_domain(ctx, N, &log_n))) return rc;
+  if (n_coeffs > N) return fail(ctx, PLK_ERR_LENGTH, "more coefficients than domain points");
+  if (!sigma_coeffs || !wire_coeffs || !out_host || (!z_coeffs && n_coeffs)) return fail(ctx, PLK_ERR_ARG, "null pointer");
+  Staged st(ctx);
+  const uint64_t* in[9]; uint64_t* ev[9];
+  const uint64_t* host_cols[9] = {z_coeffs, sigma_coeffs[0], sigma_coeffs[1], sigma_coeffs[2], sigma_coeffs[3],
+                                  wire_coeffs[0], wire_coeffs[1], wire_coeffs[2], wire_coeffs[3]};
+  for (int b = 0; b < 9; ++b) {
+    if (!host_cols[b] && n_coeffs) return fail(ctx, PLK_ERR_ARG, "null column pointer");
+    void *d, *e; if ((rc = st.upload(host_cols[b], n_coeffs * ELEM, &d))) return rc; if ((rc = st.alloc(N * ELEM, &e))) return rc;
+    in[b] = (const uint64_t*)d; ev[b] = (uint64_t*)e;
+  }
+  if ((rc = launch_ntt(ctx, ctx->stream, in, nullptr, 9, n_coeffs, N, false, ev))) return rc;
+  const uint64_t* sg[4] = {ev[1], ev[2], ev[3], ev[4]};
+  const uint64_t* w[4] = {ev[5], ev[6], ev[7], ev[8]};
+  void* d_out; if ((rc = st.alloc(N * ELEM, &d_out))) return rc;
+  if ((rc = launch_perm_eval(ctx, ctx->stream, ev[0], sg, w, N, beta, gamma, z_shift, (uint64_t*)d_out))) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(out_host, d_out, N * ELEM, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return PLK_OK;
+}
+
+int plk_round23(plk_ctx* ctx, const uint64_t* const wires[4], const uint64_t* const sel[9], const uint64_t* const sigma[4], size_t n,
+                size_t N, const uint64_t beta[4], const uint64_t gamma[4], size_t z_shift, uint64_t* z_out, uint64_t* gate_out,
+                uint64_t* perm_out) {
+  int rc = use_device(ctx), l1, l2;
+  if (rc) return rc;
+  if ((rc = check_domain(ctx, n, &l1))) return rc;
+  if ((rc = check_domain(ctx, N, &l2))) return rc;
+  if (!wires || !sigma) return fail(ctx, PLK_ERR_ARG, "null pointer");
+  Staged st(ctx);
+  const uint64_t* w[4]; const uint64_t* sg[4]; const uint64_t* s[9] = {nullptr};
+  for (int k = 0; k < 4; ++k) {
+    if (!wires[k] || !sigma[k]) return fail(ctx, PLK_ERR_ARG, "null column pointer");
+    void *d, *e; if ((rc = st.upload(wires[k], n * ELEM, &d))) return rc; if ((rc = st.upload(sigma[k], n * 8, &e))) return rc;
+    w[k] = (const uint64_t*)d; sg[k] = (const uint64_t*)e;
+  }
+  for (int k = 0; k < 9; ++k) {
+    if (!sel || !sel[k]) continue;
+    void* d; if ((rc = st.upload(sel[k], n * ELEM, &d))) return rc;
+    s[k] = (const uint64_t*)d;
+  }
+  void *dz, *dg, *dp;
+  if ((rc = st.alloc((n + 1) * ELEM, &dz))) return rc;
+  if ((rc = st.alloc(N * ELEM, &dg))) return rc;
+  if ((rc = st.alloc(N * ELEM, &dp))) return rc;
+  if ((rc = launch_round23(ctx, ctx->stream, w, s, sg, n, N, beta, gamma, z_shift, (uint64_t*)dz, (uint64_t*)dg, (uint64_t*)dp))) return rc;
+  if ((rc = fetch_status(ctx, ctx->stream))) return rc;
+  if (z_out) HIP_TRY(ctx, hipMemcpyAsync(z_out, dz, (n + 1) * ELEM, hipMemcpyDeviceToHost, ctx->stream));
+  if (gate_out) HIP_TRY(ctx, hipMemcpyAsync(gate_out, dg, N * ELEM, hipMemcpyDeviceToHost, ctx->stream));
+  if (perm_out) HIP_TRY(ctx, hipMemcpyAsync(perm_out, dp, N * ELEM, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return PLK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,184 @@
+// Permutation grand product Z as a device-wide parallel prefix product.
+//
+// Reference: build_grand_product_evaluation_polynomial, src/permutation_polynomial.rs:217-261.
+//   z[0] = 1, z[j+1] = z[j] * num_j / den_j,
+//   num_j = prod_k (v_k[j] + beta * v_k[sigma_k[j]] + gamma)   (:235-245, value at the permuted ROW)
+//   den_j = prod_k (v_k[j] + beta * j + gamma)                 (:249-254, bare row index)
+// The reference inverts den_j once per row (:258).  Here z[j+1] = P_j * S_{j+1} / D with
+// P_j = prod_{i<=j} num_i, S_{j+1} = prod_{i>j} den_i, D = prod_i den_i: one prefix scan,
+// one suffix scan and ONE field inversion for the whole column (Montgomery's batch-inversion
+// identity applied to the running denominators).  The value is the same field element.
+//
+// A zero den_j makes the reference panic (`unwrap`, :258) and sigma_k[j] >= n is a slice
+// panic (:235-238); both are recorded in `GpStatus` (smallest offending row).
+#pragma once
+#include "field.cuh"
+
+namespace plk {
+
+constexpr int GP_THREADS = 256;
+constexpr int GP_ITEMS = 4;
+constexpr int GP_BLOCK_ROWS = GP_THREADS * GP_ITEMS;
+constexpr int GP_SCAN_THREADS = 1024;
+
+struct GpStatus {
+  unsigned long long zero_den_row;   // ~0ull = none
+  unsigned long long bad_sigma_row;  // ~0ull = none
+};
+
+struct GpCols {
+  const uint64_t* v[4];      // wire value columns, n elements each
+  const uint64_t* sigma[4];  // permutation index columns, n u64 each
+};
+
+__device__ __forceinline__ Fe fe_shfl(const Fe& v, int src_lane) {
+  Fe r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.l[i] = __shfl(v.l[i], src_lane);
+  return r;
+}
+
+// Inclusive scan (operator = field multiplication) of one value per thread across the
+// workgroup, in thread order (REVERSE = false) or reversed thread order (REVERSE = true).
+// `lds` holds one element per wave.  Returns the inclusive result; *total = product of all.
+template <int THREADS, bool REVERSE>
+__device__ __forceinline__ Fe block_scan_mul(Fe v, Fe* lds, Fe* total) {
+  constexpr int WAVES = THREADS / 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int src = REVERSE ? lane + d : lane - d;
+    const Fe o = fe_shfl(v, src & 63);
+    if (REVERSE ? (src < 64) : (src >= 0)) v = fe_mul(v, o);
+  }
+  if (lane == (REVERSE ? 0 : 63)) lds[wave] = v;
+  __syncthreads();
+  Fe carry = fe_one(), all = fe_one();
+  for (int w = 0; w < WAVES; ++w) {
+    const Fe t = lds[w];
+    all = fe_mul(all, t);
+    if (REVERSE ? (w > wave) : (w < wave)) carry = fe_mul(carry, t);
+  }
+  __syncthreads();
+  *total = all;
+  return fe_mul(v, carry);
+}
+
+// Kernel 1: per-row numerator / denominator terms and per-block products.
+__global__ __launch_bounds__(GP_THREADS) void gp_terms_kernel(GpCols cols, uint64_t n, Fe beta, Fe gamma, Fe beta_r2,
+                                                              uint64_t* num, uint64_t* den,
+                                                              uint64_t* block_num, uint64_t* block_den,
+                                                              GpStatus* status) {
+  __shared__ Fe lds[GP_THREADS / 64];
+  const uint64_t row0 = ((uint64_t)blockIdx.x * GP_THREADS + threadIdx.x) * GP_ITEMS;
+  Fe pn = fe_one(), pd = fe_one();
+#pragma unroll 1
+  for (int it = 0; it < GP_ITEMS; ++it) {
+    const uint64_t j = row0 + it;
+    if (j >= n) break;
+    // beta * F::from(j): j as a raw integer times beta * R^2 / R
+    Fe jraw = fe_zero(); jraw.l[0] = (uint32_t)j; jraw.l[1] = (uint32_t)(j >> 32);
+    const Fe bj_g = fe_add(fe_mul(jraw, beta_r2), gamma);
+    Fe nj = fe_one(), dj = fe_one();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const Fe v = fe_load(cols.v[k], j);
+      uint64_t s = cols.sigma[k][j];
+      if (s >= n) { atomicMin(&status->bad_sigma_row, (unsigned long long)j); s = 0; }
+      const Fe vs = fe_load(cols.v[k], s);
+      const Fe tn = fe_add(fe_add(v, fe_mul(beta, vs)), gamma);
+      const Fe td = fe_add(v, bj_g);
+      nj = (k == 0) ? tn : fe_mul(nj, tn);
+      dj = (k == 0) ? td : fe_mul(dj, td);
+    }
+    if (fe_is_zero(dj)) atomicMin(&status->zero_den_row, (unsigned long long)j);
+    fe_store(num, j, nj);
+    fe_store(den, j, dj);
+    pn = fe_mul(pn, nj);
+    pd = fe_mul(pd, dj);
+  }
+  Fe tot_n, tot_d;
+  block_scan_mul<GP_THREADS, false>(pn, lds, &tot_n);
+  block_scan_mul<GP_THREADS, false>(pd, lds, &tot_d);
+  if (threadIdx.x == 0) { fe_store(block_num, blockIdx.x, tot_n); fe_store(block_den, blockIdx.x, tot_d); }
+}
+
+// Kernel 2 (one workgroup): exclusive prefix of the block numerators, exclusive suffix of the
+// block denominators, and 1/D folded into the prefix.  In place.
+__global__ __launch_bounds__(GP_SCAN_THREADS) void gp_block_scan_kernel(uint64_t* block_num, uint64_t* block_den, uint32_t nb) {
+  __shared__ Fe lds[GP_SCAN_THREADS / 64];
+  __shared__ Fe inv_total;
+  const uint32_t per = (nb + GP_SCAN_THREADS - 1) / GP_SCAN_THREADS;
+  const uint32_t lo = threadIdx.x * per;
+  const uint32_t hi = min(lo + per, nb);
+  Fe pn = fe_one(), pd = fe_one();
+  for (uint32_t b = lo; b < hi; ++b) { pn = fe_mul(pn, fe_load(block_num, b)); pd = fe_mul(pd, fe_load(block_den, b)); }
+  Fe tot_n, tot_d;
+  const Fe inc_n = block_scan_mul<GP_SCAN_THREADS, false>(pn, lds, &tot_n);
+  const Fe inc_d = block_scan_mul<GP_SCAN_THREADS, true>(pd, lds, &tot_d);
+  if (threadIdx.x == 0) inv_total = fe_inverse(tot_d);   // zero stays zero; the status word carries the error
+  __syncthreads();
+  // exclusive carries of this thread's chunk: inclusive result with the own chunk divided out is
+  // not available (no division), so rebuild them from the neighbours' inclusive values
+  Fe ex_n = fe_shfl(inc_n, (threadIdx.x - 1) & 63);
+  Fe ex_d = fe_shfl(inc_d, (threadIdx.x + 1) & 63);
+  // lane 0 / lane 63 need the neighbouring wave's value: pass through LDS
+  __shared__ Fe edge_n[GP_SCAN_THREADS / 64], edge_d[GP_SCAN_THREADS / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 63) edge_n[wave] = inc_n;
+  if (lane == 0) edge_d[wave] = inc_d;
+  __syncthreads();
+  if (lane == 0) ex_n = wave == 0 ? fe_one() : edge_n[wave - 1];
+  if (lane == 63) ex_d = wave == GP_SCAN_THREADS / 64 - 1 ? fe_one() : edge_d[wave + 1];
+  Fe run = fe_mul(ex_n, inv_total);
+  for (uint32_t b = lo; b < hi; ++b) { const Fe t = fe_load(block_num, b); fe_store(block_num, b, run); run = fe_mul(run, t); }
+  run = ex_d;
+  for (uint32_t b = hi; b > lo; --b) { const Fe t = fe_load(block_den, b - 1); fe_store(block_den, b - 1, run); run = fe_mul(run, t); }
+}
+
+// Kernel 3: in-block prefix / suffix scans combined with the block carries -> z[1..n]; z[0] = 1.
+__global__ __launch_bounds__(GP_THREADS) void gp_finish_kernel(const uint64_t* num, const uint64_t* den, uint64_t n,
+                                                               const uint64_t* block_num_ex, const uint64_t* block_den_ex,
+                                                               uint64_t* z) {
+  __shared__ Fe lds[GP_THREADS / 64];
+  __shared__ Fe edge[GP_THREADS / 64];
+  const uint64_t row0 = ((uint64_t)blockIdx.x * GP_THREADS + threadIdx.x) * GP_ITEMS;
+  Fe nv[GP_ITEMS], dv[GP_ITEMS];
+#pragma unroll
+  for (int it = 0; it < GP_ITEMS; ++it) {
+    const uint64_t j = row0 + it;
+    nv[it] = j < n ? fe_load(num, j) : fe_one();
+    dv[it] = j < n ? fe_load(den, j) : fe_one();
+  }
+  // thread-local inclusive prefix of num, inclusive suffix of den
+#pragma unroll
+  for (int it = 1; it < GP_ITEMS; ++it) nv[it] = fe_mul(nv[it - 1], nv[it]);
+#pragma unroll
+  for (int it = GP_ITEMS - 2; it >= 0; --it) dv[it] = fe_mul(dv[it + 1], dv[it]);
+  Fe tot;
+  const Fe inc_n = block_scan_mul<GP_THREADS, false>(nv[GP_ITEMS - 1], lds, &tot);
+  const Fe inc_d = block_scan_mul<GP_THREADS, true>(dv[0], lds, &tot);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // exclusive carries: previous thread's inclusive prefix, next thread's inclusive suffix
+  Fe ex_n = fe_shfl(inc_n, (lane - 1) & 63);
+  Fe ex_d = fe_shfl(inc_d, (lane + 1) & 63);
+  if (lane == 63) lds[wave] = inc_n;
+  if (lane == 0) edge[wave] = inc_d;
+  __syncthreads();
+  if (lane == 0) ex_n = wave == 0 ? fe_one() : lds[wave - 1];
+  if (lane == 63) ex_d = wave == GP_THREADS / 64 - 1 ? fe_one() : edge[wave + 1];
+  const Fe cn = fe_mul(ex_n, fe_load(block_num_ex, blockIdx.x));   // includes 1/D
+  const Fe cd = fe_mul(ex_d, fe_load(block_den_ex, blockIdx.x));
+  // z[j+1] = (cn * prefix_num_j) * (suffix_den_{j+1} * cd)
+#pragma unroll
+  for (int it = 0; it < GP_ITEMS; ++it) {
+    const uint64_t j = row0 + it;
+    if (j >= n) break;
+    const Fe p = fe_mul(cn, nv[it]);
+    const Fe s = it + 1 < GP_ITEMS ? fe_mul(dv[it + 1], cd) : cd;
+    fe_store(z, j + 1, fe_mul(p, s));
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) fe_store(z, 0, fe_one());
+}
+
+}  // namespace plk

@@ -1,0 +1,133 @@
+"""Seeded synthetic circuits (host side, numpy only) for parity tests and the benchmark.
+
+A circuit here is exactly what the hot path consumes: a `GateEvaluationTable` (4 wire columns +
+one-hot selector columns) and a `PermutationTable` (4 index columns).  The reference has no
+trace builder (nothing calls `ExecutionTable::push_row`, src/execution_trace.rs:27-29), so the
+columns are generated directly.
+
+Generator: splitmix64.  Stream `k` of circuit `c` is seeded with SEED_BASE + k + 1000003 * c.
+  wire column k (k = 0..3): element j = outputs 4j..4j+3 as little-endian limbs, reduced mod p
+      by subtraction; the reduced value is used AS the Montgomery residue (any residue < p is
+      a valid element, and no conversion pass is needed at 2^24 rows).
+  sigma column k (stream 4 + k): the stable argsort of n outputs — a uniform permutation of [0, n).
+  selectors (stream 8): row j gets kind (output_j mod 9); that column holds one, the others zero.
+  beta, gamma (streams 9, 10): one element each, forced non-zero.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+from .api import AST_KINDS, GateEvaluationTable, PermutationTable
+
+SEED_BASE = 0x504C4F4E4B  # "PLONK"
+CIRCUIT_STRIDE = 1000003
+
+P_INT = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+P_LIMBS = np.array([(P_INT >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+ONE_MONT_INT = (1 << 256) % P_INT
+ONE_MONT = np.array([(ONE_MONT_INT >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def splitmix64(seed: int, count: int) -> np.ndarray:
+    """The first `count` outputs of splitmix64 seeded with `seed` (vectorised, wrapping uint64)."""
+    with np.errstate(over="ignore"):
+        idx = np.arange(1, count + 1, dtype=np.uint64)
+        z = np.uint64(seed & 0xFFFFFFFFFFFFFFFF) + idx * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def _geq_p(a: np.ndarray) -> np.ndarray:
+    """a >= p, limb-wise on (n, 4) uint64."""
+    ge = np.ones(a.shape[0], dtype=bool)
+    decided = np.zeros(a.shape[0], dtype=bool)
+    for i in (3, 2, 1, 0):
+        gt, lt = a[:, i] > P_LIMBS[i], a[:, i] < P_LIMBS[i]
+        ge = np.where(~decided & lt, False, ge)
+        decided |= gt | lt
+    return ge
+
+
+def _sub_p(a: np.ndarray, mask: np.ndarray) -> np.ndarray:
+    out = a.copy()
+    borrow = np.zeros(a.shape[0], dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        for i in range(4):
+            sub = np.where(mask, P_LIMBS[i], np.uint64(0))
+            d = a[:, i] - sub
+            b1 = (a[:, i] < sub).astype(np.uint64)
+            d2 = d - borrow
+            b2 = (d < borrow).astype(np.uint64)
+            out[:, i] = d2
+            borrow = b1 | b2
+    return out
+
+
+def reduce_mod_p(a: np.ndarray) -> np.ndarray:
+    """(n, 4) uint64 256-bit integers -> reduced below p (2^256 < 3p, so two subtractions suffice)."""
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    for _ in range(2):
+        a = _sub_p(a, _geq_p(a))
+    return a
+
+
+def random_elements(seed: int, n: int) -> np.ndarray:
+    return reduce_mod_p(splitmix64(seed, 4 * n).reshape(n, 4))
+
+
+def random_permutation(seed: int, n: int) -> np.ndarray:
+    return np.argsort(splitmix64(seed, n), kind="stable").astype(np.uint64)
+
+
+@dataclass
+class Circuit:
+    n: int
+    table: GateEvaluationTable
+    perm: PermutationTable
+    beta: np.ndarray
+    gamma: np.ndarray
+
+
+def make_circuit(n: int, circuit_id: int = 0, kinds=AST_KINDS) -> Circuit:
+    base = SEED_BASE + CIRCUIT_STRIDE * circuit_id
+    wires = [random_elements(base + k, n) for k in range(4)]
+    sigmas = [random_permutation(base + 4 + k, n) for k in range(4)]
+    kind_of_row = (splitmix64(base + 8, n) % np.uint64(len(AST_KINDS))).astype(np.int64)
+    selectors = {}
+    for k, name in enumerate(AST_KINDS):
+        if name not in kinds:
+            continue
+        col = np.zeros((n, 4), dtype=np.uint64)
+        col[kind_of_row == k] = ONE_MONT
+        selectors[name] = col
+    beta = random_elements(base + 9, 1)[0]
+    gamma = random_elements(base + 10, 1)[0]
+    if not beta.any():
+        beta = ONE_MONT.copy()
+    if not gamma.any():
+        gamma = ONE_MONT.copy()
+    return Circuit(n, GateEvaluationTable(*wires, selectors=selectors), PermutationTable(*sigmas), beta, gamma)
+
+
+# ---- conversions between Python integers and limb rows (small inputs, tests and fixtures)
+
+R_INV_INT = pow(1 << 256, -1, P_INT)
+
+
+def ints_to_mont(values) -> np.ndarray:
+    out = np.empty((len(values), 4), dtype=np.uint64)
+    for i, v in enumerate(values):
+        m = (int(v) % P_INT) * ONE_MONT_INT % P_INT
+        for j in range(4):
+            out[i, j] = (m >> (64 * j)) & 0xFFFFFFFFFFFFFFFF
+    return out
+
+
+def mont_to_ints(a: np.ndarray):
+    a = np.asarray(a, dtype=np.uint64).reshape(-1, 4)
+    return [sum(int(a[i, j]) << (64 * j) for j in range(4)) * R_INV_INT % P_INT for i in range(a.shape[0])]
