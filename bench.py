@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""Benchmark of the PLONK polynomial hot path on MI355X.
+
+One step = prover rounds 2+3 for one synthetic circuit of n = 2^20 rows (BASELINE.json config 3):
+grand product Z, interpolation of the 18 columns (4 wires, 9 selectors, 4 sigma, Z), their
+low-degree extension to the N = 4n domain (wires evaluated once), gate-constraint and
+permutation-constraint evaluation.  Inputs are resident in HBM before the timed region.
+
+    python bench.py --gpus N --steps K --warmup W
+
+With N > 1 (one process per GPU, launched through torch.distributed.run) every rank proves its
+own circuit per step (batched-proof mode, no data-path collective): weak scaling.  `value` is
+the time per circuit over the whole job, ms_per_step / N.
+
+Prints ONE JSON line (rank 0).
+"""
+from __future__ import annotations
+
+import argparse
+import glob
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak
+NTT_ROOFLINE_GELEM = HBM_PEAK_GBS / 64.0   # 64 algorithmic bytes per element per transform
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log-n", type=int, default=20, help="log2 of the number of rows")
+    ap.add_argument("--blowup", type=int, default=4, help="evaluation domain = blowup * n")
+    ap.add_argument("--cpu-sample-log-n", type=int, default=16, help="rows of the CPU-baseline sample (log2)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(log_n_full: int, blowup: int, sample_log_n: int):
+    """The C restatement of the reference algorithm (oracle/plonk_oracle.c) timed on this host
+    on a smaller circuit of the same shape, scaled linearly in the number of rows."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import c_oracle as co
+    from plonk_amd import synth
+    ns = 1 << sample_log_n
+    c = synth.make_circuit(ns, circuit_id=0)
+    threads = min(co.num_threads(), 16)
+    co.set_num_threads(threads)
+    t0 = time.perf_counter()
+    co.round23(c.table.wires(), c.table.selectors, c.perm.columns(), blowup * ns, c.beta, c.gamma)
+    dt = time.perf_counter() - t0
+    scale = float(1 << (log_n_full - sample_log_n))
+    return {
+        "value": round(dt * 1e3 * scale, 1), "unit": "ms", "cores": threads, "kind": "port",
+        "sample": f"one round 2+3 at n=2^{sample_log_n}, N=2^{sample_log_n + blowup.bit_length() - 1} took {dt:.2f} s "
+                  f"(transforms on {threads} OpenMP threads, grand-product and constraint loops single-threaded as in the "
+                  f"reference); scaled x{int(scale)} by row count (ignores the log factor of the transforms)",
+    }
+
+
+def pmc_traffic(label: str):
+    """HBM bytes per launch of the dominant kernel from a committed rocprofv3 --pmc summary, if any."""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.json")), reverse=True):
+        try:
+            with open(path) as f:
+                data = json.load(f)
+            if label in data:
+                return data[label]["hbm_bytes_per_launch"], os.path.basename(path)
+        except Exception:
+            continue
+    return None, None
+
+
+def main():
+    args = parse_args()
+    import torch
+    from plonk_amd import synth
+    from plonk_amd.device import DeviceProver
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    n, N = 1 << args.log_n, args.blowup << args.log_n
+
+    prover = DeviceProver(local_rank)
+    circuit = synth.make_circuit(n, circuit_id=rank)
+    dc = prover.upload(circuit)
+    out = (prover.empty(n + 1), prover.empty(N), prover.empty(N))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        prover.round23(dc, N, out=out)
+    prover.status()  # also the first correctness gate: no zero denominator, sigma in range
+
+    barrier()
+    prover.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        prover.round23(dc, N, out=out)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = prover.profile_end()
+    prover.status()
+
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=prover.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt * 1e3 / args.steps
+
+    if rank == 0:
+        S = len(circuit.table.selectors)
+        ncol = 4 + S + 5
+        # dominant kernel label by device time
+        dom = max(prof, key=lambda r: r["total_ms"]) if prof else None
+        roofline = None
+        if dom and dom["total_ms"] > 0:
+            per_launch_ms = dom["total_ms"] / dom["launches"]
+            per_launch_bytes = dom["alg_bytes"] / dom["launches"]
+            achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
+            traffic, src = pmc_traffic(dom["label"])
+            roofline = {"bound": "hbm", "kernel": dom["label"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                        "traffic_source": src, "avg_launch_ms": round(per_launch_ms, 4),
+                        "alg_bytes_per_launch": per_launch_bytes,
+                        "note": "a transform of N points over B columns is 64*N*B algorithmic bytes (160*n*B for an n -> 4n "
+                                "extension); each of its P launches is credited 1/P of that"}
+        # whole-transform throughput of the extension (all launches of the N-point forward transform)
+        lde = [r for r in prof if f"/ntt{args.log_n + args.blowup.bit_length() - 1}" in r["label"]]
+        ntt = None
+        if lde:
+            lde_ms = sum(r["total_ms"] for r in lde) / args.steps
+            gelem = ncol * N / (lde_ms * 1e-3) / 1e9
+            ntt = {"what": f"{ncol} forward transforms, {n} coefficients -> {N} points, {len(lde)} launches each batch",
+                   "ms_per_batch": round(lde_ms, 4), "gelem_per_s": round(gelem, 3),
+                   "frac_of_hbm_roofline": round(gelem / NTT_ROOFLINE_GELEM, 4), "passes": len(lde)}
+        alg_bytes_step = (18 * 64 + 18 * 160 + 320 + 448 * args.blowup + 320 * args.blowup) * n if S == 9 else None
+        line = {
+            "metric": f"prover round 2+3 time at n=2^{args.log_n}", "value": round(ms_per_step / world, 4), "unit": "ms",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": f"round 2+3, n=2^{args.log_n}, N={args.blowup}n, S={S} selectors, 18 interpolations + "
+                                   f"18 extensions (wires evaluated once), one circuit per GPU per step",
+                       "field": "BLS12-381 Fr", "circuits_per_step": world},
+            "proofs_per_s": round(world / (ms_per_step * 1e-3), 3),
+            "step_alg_bytes": alg_bytes_step,
+            "step_frac_of_hbm_roofline": round(alg_bytes_step / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if alg_bytes_step else None,
+            "roofline": roofline, "ntt": ntt,
+            "kernels": [{"label": r["label"], "launches": r["launches"], "ms_per_step": round(r["total_ms"] / args.steps, 4),
+                         "alg_GBps": round(r["alg_bytes"] / max(r["total_ms"], 1e-9) / 1e6, 1)} for r in prof],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.log_n, args.blowup, min(args.cpu_sample_log_n, args.log_n))
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -150,6 +150,15 @@ int plk_dev_round23(plk_ctx* ctx, void* stream, const uint64_t* const wires[PLK_
  * enqueued since the last plk_dev_status (PLK_OK, PLK_ERR_ZERO_DENOMINATOR, PLK_ERR_SIGMA_RANGE). */
 int plk_dev_status(plk_ctx* ctx, void* stream);
 
+/* Per-launch timing.  Between plk_profile_begin and plk_profile_end every kernel the library
+ * launches on this context is bracketed by HIP events on its own stream.  plk_profile_end waits
+ * for the device and returns a JSON array (valid until the next call on this context) of
+ * {"label", "launches", "total_ms", "alg_bytes"} per kernel label, alg_bytes being the
+ * compulsory bytes of those launches (inputs read once + outputs written once).
+ * No counterpart in the reference. */
+void plk_profile_begin(plk_ctx* ctx);
+const char* plk_profile_end(plk_ctx* ctx);
+
 /* canonical integer limbs <-> Montgomery limbs, n elements, device pointers, out may alias in */
 int plk_dev_to_montgomery(plk_ctx* ctx, void* stream, const uint64_t* in, size_t n, uint64_t* out);
 int plk_dev_from_montgomery(plk_ctx* ctx, void* stream, const uint64_t* in, size_t n, uint64_t* out);

@@ -56,6 +56,8 @@ SIGNATURES = {
     "plk_dev_perm_constraint_eval": (C.c_int, [C.c_void_p, C.c_void_p, u64p, u64pp, u64pp, C.c_size_t, u64p, u64p, C.c_size_t, u64p]),
     "plk_dev_round23": (C.c_int, [C.c_void_p, C.c_void_p, u64pp, u64pp, u64pp, C.c_size_t, C.c_size_t, u64p, u64p, C.c_size_t, u64p, u64p, u64p]),
     "plk_dev_status": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "plk_profile_begin": (None, [C.c_void_p]),
+    "plk_profile_end": (C.c_char_p, [C.c_void_p]),
     "plk_dev_to_montgomery": (C.c_int, [C.c_void_p, C.c_void_p, u64p, C.c_size_t, u64p]),
     "plk_dev_from_montgomery": (C.c_int, [C.c_void_p, C.c_void_p, u64p, C.c_size_t, u64p]),
 }
@@ -68,6 +70,24 @@ class LibraryMissing(RuntimeError):
 _lib: Optional[C.CDLL] = None
 
 
+def _preload_hip_runtime() -> None:
+    """A PyTorch ROCm wheel bundles its own HIP runtime (torch/lib/libamdhip64.so, same soname as
+    the system one).  Two HIP runtimes in one process cannot both open the GPU, so when torch is
+    installed its copy is loaded first and libplonk_hip.so binds to it by soname; a later
+    `import torch` then finds that same file already mapped.  Without torch the system runtime
+    on the library's RUNPATH is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def load() -> C.CDLL:
     """Load libplonk_hip.so and type every entry point.  Raises LibraryMissing if it is absent."""
     global _lib
@@ -77,6 +97,7 @@ def load() -> C.CDLL:
         raise LibraryMissing(
             f"{LIB_PATH} not found: build it with `make -C plonk_amd/csrc` (or __graft_entry__.build()); "
             "there is no CPU fallback")
+    _preload_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = header and library disagree

@@ -47,6 +47,12 @@ struct plk_ctx {
   GpStatus* status_host = nullptr;  // pinned
   std::string last_error;
   long long last_row = -1;
+  // optional per-launch timing (plk_profile_*): one event pair per kernel launch
+  bool profiling = false;
+  struct ProfRec { std::string label; hipEvent_t e0, e1; double alg_bytes; };
+  std::vector<ProfRec> prof;
+  std::vector<hipEvent_t> event_pool;
+  std::string prof_report;
 };
 
 namespace {
@@ -55,6 +61,23 @@ int fail(plk_ctx* ctx, int code, const std::string& msg) {
   if (ctx) ctx->last_error = msg;
   return code;
 }
+
+// Brackets one kernel launch with HIP events on the launch stream when profiling is on.
+struct ProfScope {
+  plk_ctx* ctx; hipStream_t s; size_t idx = (size_t)-1;
+  ProfScope(plk_ctx* c, hipStream_t st, const std::string& label, double alg_bytes) : ctx(c), s(st) {
+    if (!ctx->profiling) return;
+    hipEvent_t ev[2];
+    for (auto& e : ev) {
+      if (!ctx->event_pool.empty()) { e = ctx->event_pool.back(); ctx->event_pool.pop_back(); }
+      else if (hipEventCreate(&e) != hipSuccess) return;
+    }
+    ctx->prof.push_back({label, ev[0], ev[1], alg_bytes});
+    idx = ctx->prof.size() - 1;
+    (void)hipEventRecord(ev[0], s);
+  }
+  ~ProfScope() { if (idx != (size_t)-1) (void)hipEventRecord(ctx->prof[idx].e1, s); }
+};
 
 #define HIP_TRY(ctx, expr)                                                                          \
   do {                                                                                              \
@@ -190,6 +213,10 @@ int launch_ntt(plk_ctx* ctx, hipStream_t s, const uint64_t* const* in, const uin
   }
   const size_t lds_bytes = 2 * NTT_TILE * sizeof(uint4);
   const int P = plan->npass;
+  // algorithmic bytes of the whole transform group (read the inputs once, write the outputs once),
+  // attributed in equal shares to its P launches
+  const double alg_share = (32.0 * (double)n_in + 32.0 * (double)N) * (double)batch / P;
+  const std::string tag = std::string(inverse ? "/intt" : "/ntt") + std::to_string(log_n) + (n_in < N ? "lde" : "");
   // non-final passes
   int log_inner = log_n;
   for (int p = 0; p + 1 < P; ++p) {
@@ -210,6 +237,7 @@ int launch_ntt(plk_ctx* ctx, hipStream_t s, const uint64_t* const* in, const uin
       a.batch.out[b] = tmp + b * N * 4;
     }
     const unsigned tiles = 1u << (log_n - lr - a.log_c);
+    ProfScope ps(ctx, s, "ntt_pass_kernel" + tag + "/p" + std::to_string(p), alg_share);
     hipLaunchKernelGGL(ntt_pass_kernel, dim3(tiles, (unsigned)batch), dim3(NTT_THREADS), lds_bytes, s, a);
     HIP_TRY(ctx, hipGetLastError());
   }
@@ -229,6 +257,7 @@ int launch_ntt(plk_ctx* ctx, hipStream_t s, const uint64_t* const* in, const uin
       a.batch.out[b] = out[b];
     }
     const unsigned tiles = 1u << (log_n - a.log_r - a.log_c);
+    ProfScope ps(ctx, s, "ntt_final_kernel" + tag, alg_share);
     hipLaunchKernelGGL(ntt_final_kernel, dim3(tiles, (unsigned)batch), dim3(NTT_THREADS), lds_bytes, s, a);
     HIP_TRY(ctx, hipGetLastError());
   }
@@ -265,13 +294,22 @@ int launch_grand_product(plk_ctx* ctx, hipStream_t s, const uint64_t* const wire
   if ((rc = ws_get(ctx, "gp_bnum", nb * ELEM, &bn))) return rc;
   if ((rc = ws_get(ctx, "gp_bden", nb * ELEM, &bd))) return rc;
   const Fe beta_r2 = fe_mul(beta, fe_r2());
+  {
+  ProfScope ps(ctx, s, "gp_terms_kernel", 288.0 * (double)n);   // 4 values + 4 indices + 4 gathers per row
   hipLaunchKernelGGL(gp_terms_kernel, dim3((unsigned)nb), dim3(GP_THREADS), 0, s, cols, (uint64_t)n, beta, gamma, beta_r2,
                      (uint64_t*)num, (uint64_t*)den, (uint64_t*)bn, (uint64_t*)bd, ctx->status_dev);
+  }
   HIP_TRY(ctx, hipGetLastError());
+  {
+  ProfScope ps(ctx, s, "gp_block_scan_kernel", 0.0);
   hipLaunchKernelGGL(gp_block_scan_kernel, dim3(1), dim3(GP_SCAN_THREADS), 0, s, (uint64_t*)bn, (uint64_t*)bd, (uint32_t)nb);
+  }
   HIP_TRY(ctx, hipGetLastError());
+  {
+  ProfScope ps(ctx, s, "gp_finish_kernel", 32.0 * (double)(n + 1));   // the z column
   hipLaunchKernelGGL(gp_finish_kernel, dim3((unsigned)nb), dim3(GP_THREADS), 0, s, (const uint64_t*)num, (const uint64_t*)den,
                      (uint64_t)n, (const uint64_t*)bn, (const uint64_t*)bd, z_out);
+  }
   HIP_TRY(ctx, hipGetLastError());
   return PLK_OK;
 }
@@ -284,7 +322,12 @@ int launch_gate_eval(plk_ctx* ctx, hipStream_t s, const uint64_t* const w[4], co
   for (int k = 0; k < 4; ++k) { if (!w[k]) return fail(ctx, PLK_ERR_ARG, "null wire column"); cols.w[k] = w[k]; }
   for (int k = 0; k < 9; ++k) cols.s[k] = sel ? sel[k] : nullptr;
   const unsigned blocks = (unsigned)((N + EW_THREADS - 1) / EW_THREADS);
+  int ncols = 5;
+  for (int k = 0; k < 9; ++k) ncols += cols.s[k] != nullptr;
+  {
+  ProfScope ps(ctx, s, "gate_constraint_kernel", 32.0 * ncols * (double)N);
   hipLaunchKernelGGL(gate_constraint_kernel, dim3(blocks), dim3(EW_THREADS), 0, s, cols, (uint64_t)N, out);
+  }
   HIP_TRY(ctx, hipGetLastError());
   return PLK_OK;
 }
@@ -305,8 +348,11 @@ int launch_perm_eval(plk_ctx* ctx, hipStream_t s, const uint64_t* z, const uint6
   }
   const Fe beta_r2 = fe_mul(beta, fe_r2());
   const unsigned blocks = (unsigned)((N + EW_THREADS - 1) / EW_THREADS);
+  {
+  ProfScope ps(ctx, s, "perm_constraint_kernel", 320.0 * (double)N);
   hipLaunchKernelGGL(perm_constraint_kernel, dim3(blocks), dim3(EW_THREADS), 0, s, cols, (uint64_t)N, beta, gamma, beta_r2,
                      (uint64_t)z_shift, out);
+  }
   HIP_TRY(ctx, hipGetLastError());
   return PLK_OK;
 }
@@ -412,17 +458,30 @@ int plk_ctx_create(int device, plk_ctx** out) {
   if (!out) return PLK_ERR_ARG;
   *out = nullptr;
   int count = 0;
-  if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return PLK_ERR_HIP;
+  hipError_t ec = hipGetDeviceCount(&count);
+  if (ec != hipSuccess || device < 0 || device >= count) {
+    fprintf(stderr, "plk_ctx_create: device %d not available (hipGetDeviceCount: %s, count %d)\n", device,
+            hipGetErrorString(ec), count);
+    return PLK_ERR_HIP;
+  }
   plk_ctx* ctx = new (std::nothrow) plk_ctx();
   if (!ctx) return PLK_ERR_NOMEM;
   ctx->device = device;
-  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipMalloc((void**)&ctx->status_dev, sizeof(GpStatus)) != hipSuccess ||
-      hipHostMalloc((void**)&ctx->status_host, sizeof(GpStatus)) != hipSuccess ||
-      hipMemset(ctx->status_dev, 0xff, sizeof(GpStatus)) != hipSuccess) {
-    plk_ctx_destroy(ctx);
-    return PLK_ERR_HIP;
-  }
+#define CTX_TRY(expr)                                                                           \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess) {                                                                     \
+      fprintf(stderr, "plk_ctx_create: %s failed: %s\n", #expr, hipGetErrorString(e_));        \
+      plk_ctx_destroy(ctx);                                                                     \
+      return PLK_ERR_HIP;                                                                       \
+    }                                                                                           \
+  } while (0)
+  CTX_TRY(hipSetDevice(device));
+  CTX_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  CTX_TRY(hipMalloc((void**)&ctx->status_dev, sizeof(GpStatus)));
+  CTX_TRY(hipHostMalloc((void**)&ctx->status_host, sizeof(GpStatus)));
+  CTX_TRY(hipMemset(ctx->status_dev, 0xff, sizeof(GpStatus)));
+#undef CTX_TRY
   *out = ctx;
   return PLK_OK;
 }
@@ -437,6 +496,8 @@ void plk_ctx_destroy(plk_ctx* ctx) {
     for (DevBuf* b : {&p.master, &p.hi, &p.hi_scaled, &p.lo, &p.scale}) if (b->p) (void)hipFree(b->p);
   }
   for (auto& kv : ctx->ws) if (kv.second.p) (void)hipFree(kv.second.p);
+  for (auto& r : ctx->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  for (auto& e : ctx->event_pool) (void)hipEventDestroy(e);
   if (ctx->status_dev) (void)hipFree(ctx->status_dev);
   if (ctx->status_host) (void)hipHostFree(ctx->status_host);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -467,6 +528,45 @@ void plk_field_constants(uint64_t modulus[4], uint64_t one[4], uint64_t r2[4]) {
     if (one) one[i] = (uint64_t)Field::ONE[2 * i] | ((uint64_t)Field::ONE[2 * i + 1] << 32);
     if (r2) r2[i] = (uint64_t)Field::R2[2 * i] | ((uint64_t)Field::R2[2 * i + 1] << 32);
   }
+}
+
+// ---------------------------------------------------------------------------- profiling
+
+void plk_profile_begin(plk_ctx* ctx) {
+  if (!ctx) return;
+  for (auto& r : ctx->prof) { ctx->event_pool.push_back(r.e0); ctx->event_pool.push_back(r.e1); }
+  ctx->prof.clear();
+  ctx->profiling = true;
+}
+
+const char* plk_profile_end(plk_ctx* ctx) {
+  if (!ctx) return "[]";
+  ctx->profiling = false;
+  (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  struct Agg { size_t launches = 0; double ms = 0, bytes = 0; };
+  std::vector<std::string> order;
+  std::map<std::string, Agg> agg;
+  for (auto& r : ctx->prof) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) ms = 0;
+    if (!agg.count(r.label)) order.push_back(r.label);
+    Agg& a = agg[r.label];
+    a.launches += 1; a.ms += ms; a.bytes += r.alg_bytes;
+    ctx->event_pool.push_back(r.e0); ctx->event_pool.push_back(r.e1);
+  }
+  ctx->prof.clear();
+  std::string out = "[";
+  char buf[512];
+  for (size_t i = 0; i < order.size(); ++i) {
+    const Agg& a = agg[order[i]];
+    snprintf(buf, sizeof buf, "%s{\"label\": \"%s\", \"launches\": %zu, \"total_ms\": %.6f, \"alg_bytes\": %.1f}",
+             i ? ", " : "", order[i].c_str(), a.launches, a.ms, a.bytes);
+    out += buf;
+  }
+  out += "]";
+  ctx->prof_report = out;
+  return ctx->prof_report.c_str();
 }
 
 // ---------------------------------------------------------------------------- device API

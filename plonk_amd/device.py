@@ -1,0 +1,128 @@
+"""Device-resident driver of the hot path: columns live in HBM as torch tensors, the library's
+`plk_dev_*` entry points are enqueued on torch's current HIP stream.
+
+torch is used for device memory, streams and (in plonk_amd.dist) collectives only; every
+arithmetic step runs in libplonk_hip.so.  A column is an `(n, 4) int64` CUDA tensor holding the
+same bytes as the `(n, 4) uint64` Montgomery limbs of the host interface; sigma is `(n,) int64`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .api import AST_KINDS, Context
+from .synth import Circuit
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.cast(C.c_void_p(t.data_ptr()), _lib.u64p) if t is not None else None
+
+
+def _table(ts: Sequence[Optional[torch.Tensor]]):
+    arr = (_lib.u64p * len(ts))()
+    for i, t in enumerate(ts):
+        arr[i] = _ptr(t)
+    return arr
+
+
+def _host_fe(x) -> np.ndarray:
+    return np.ascontiguousarray(x, dtype=np.uint64).reshape(4)
+
+
+def to_device(a: np.ndarray, device: torch.device) -> torch.Tensor:
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(device)
+
+
+def to_host(t: torch.Tensor) -> np.ndarray:
+    return t.cpu().numpy().view(np.uint64)
+
+
+@dataclass
+class DeviceCircuit:
+    n: int
+    wires: List[torch.Tensor]
+    selectors: Dict[str, torch.Tensor]
+    sigma: List[torch.Tensor]
+    beta: np.ndarray
+    gamma: np.ndarray
+
+
+class DeviceProver:
+    """One GPU's context plus helpers to run the path on device-resident columns."""
+
+    def __init__(self, device_index: int = 0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("no GPU visible: the hot path has no CPU fallback")
+        self.device = torch.device("cuda", device_index)
+        torch.cuda.set_device(self.device)
+        self.ctx = Context(device_index)
+        self.lib = self.ctx.lib
+
+    # -- plumbing
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def empty(self, rows: int) -> torch.Tensor:
+        return torch.empty((rows, 4), dtype=torch.int64, device=self.device)
+
+    def upload(self, c: Circuit) -> DeviceCircuit:
+        d = self.device
+        return DeviceCircuit(c.n, [to_device(w, d) for w in c.table.wires()],
+                             {k: to_device(v, d) for k, v in c.table.selectors.items()},
+                             [to_device(s, d) for s in c.perm.columns()], _host_fe(c.beta), _host_fe(c.gamma))
+
+    def status(self):
+        """Wait for the stream and raise if a data-dependent failure was recorded."""
+        self.ctx.check(self.lib.plk_dev_status(self.ctx.handle, self._stream()))
+
+    # -- entry points
+    def ntt_batch(self, cols: Sequence[torch.Tensor], N: int, inverse: bool = False, n_in: Optional[int] = None,
+                  kinds: Optional[Sequence[int]] = None, out: Optional[Sequence[torch.Tensor]] = None) -> List[torch.Tensor]:
+        n_in = cols[0].shape[0] if n_in is None else n_in
+        out = [self.empty(N) for _ in cols] if out is None else list(out)
+        karr = (C.c_uint32 * len(cols))(*kinds) if kinds is not None else None
+        self.ctx.check(self.lib.plk_dev_ntt_batch(self.ctx.handle, self._stream(), _table(cols), karr, len(cols), n_in, N,
+                                                  1 if inverse else 0, _table(out)))
+        return out
+
+    def grand_product(self, dc: DeviceCircuit, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        z = self.empty(dc.n + 1) if out is None else out
+        self.ctx.check(self.lib.plk_dev_grand_product(self.ctx.handle, self._stream(), _table(dc.wires), _table(dc.sigma), dc.n,
+                                                      dc.beta.ctypes.data_as(_lib.u64p), dc.gamma.ctypes.data_as(_lib.u64p), _ptr(z)))
+        return z
+
+    def gate_constraint_eval(self, wire_evals, sel_evals: Dict[str, torch.Tensor], N: int, out=None) -> torch.Tensor:
+        out = self.empty(N) if out is None else out
+        sels = [sel_evals.get(k) for k in AST_KINDS]
+        self.ctx.check(self.lib.plk_dev_gate_constraint_eval(self.ctx.handle, self._stream(), _table(wire_evals), _table(sels), N, _ptr(out)))
+        return out
+
+    def perm_constraint_eval(self, z_evals, sigma_evals, wire_evals, N: int, beta, gamma, z_shift: int = 1, out=None) -> torch.Tensor:
+        out = self.empty(N) if out is None else out
+        b, g = _host_fe(beta), _host_fe(gamma)
+        self.ctx.check(self.lib.plk_dev_perm_constraint_eval(self.ctx.handle, self._stream(), _ptr(z_evals), _table(sigma_evals),
+                                                             _table(wire_evals), N, b.ctypes.data_as(_lib.u64p),
+                                                             g.ctypes.data_as(_lib.u64p), z_shift, _ptr(out)))
+        return out
+
+    def round23(self, dc: DeviceCircuit, N: int, z_shift: int = 1, out=None):
+        """Enqueue rounds 2+3 for one circuit; returns (z [n+1], gate [N], perm [N]) device tensors."""
+        z, g, p = out if out is not None else (self.empty(dc.n + 1), self.empty(N), self.empty(N))
+        sels = [dc.selectors.get(k) for k in AST_KINDS]
+        self.ctx.check(self.lib.plk_dev_round23(self.ctx.handle, self._stream(), _table(dc.wires), _table(sels), _table(dc.sigma),
+                                                dc.n, N, dc.beta.ctypes.data_as(_lib.u64p), dc.gamma.ctypes.data_as(_lib.u64p),
+                                                z_shift, _ptr(z), _ptr(g), _ptr(p)))
+        return z, g, p
+
+    # -- per-launch timing
+    def profile_begin(self):
+        self.lib.plk_profile_begin(self.ctx.handle)
+
+    def profile_end(self) -> list:
+        return json.loads(self.lib.plk_profile_end(self.ctx.handle).decode())

@@ -1,0 +1,59 @@
+"""CPU tests of the boundary: the shared library loads without a GPU and exports exactly what
+include/plonk_hip.h declares; entry points that need no device behave."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from plonk_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "plonk_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(plk_[a-z0-9_]+)\s*\(", text)) - {"plk_builder_fn"})
+
+
+def test_header_and_binding_agree():
+    assert declared_symbols() == sorted(_lib.SIGNATURES)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    for name in declared_symbols():
+        assert hasattr(lib, name), f"{name} declared in plonk_hip.h but not exported"
+
+
+def test_no_device_entry_points():
+    lib = _lib.load()
+    assert lib.plk_strerror(0) == b"ok"
+    assert b"domain size" in lib.plk_strerror(_lib.PLK_ERR_LENGTH)
+    assert lib.plk_strerror(-12345) == b"unknown error"
+    m, one, r2 = ((C.c_uint64 * 4)() for _ in range(3))
+    lib.plk_field_constants(m, one, r2)
+    p = sum(int(m[i]) << (64 * i) for i in range(4))
+    assert p == 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+    assert sum(int(one[i]) << (64 * i) for i in range(4)) == (1 << 256) % p
+    assert sum(int(r2[i]) << (64 * i) for i in range(4)) == (1 << 512) % p
+    assert lib.plk_ctx_create(0, None) == _lib.PLK_ERR_ARG
+    assert lib.plk_last_error(None) == b"" and lib.plk_last_error_row(None) == -1
+    lib.plk_ctx_destroy(None)  # no-op
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libplonk_hip.so"))
+    with pytest.raises(_lib.LibraryMissing):
+        _lib.load()
+
+
+def test_product_path_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "plonk_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cuh", ".cpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "plonk_oracle" not in src and "c_oracle" not in src and "liboracle" not in src, f
