@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""Turns one tools/profile.sh output directory into the committed summaries under profiles/:
+  <tag>_kernel_stats.csv     rocprofv3's own --stats table, unchanged
+  <tag>_by_label.md/.json    per bench label: launches, average duration, HBM bytes from the PMC
+                             counters, VALU activity
+  <tag>_pmc_summary.json     label -> hbm_bytes_per_launch (read by bench.py for roofline.traffic)
+
+Dispatches of one round-2+3 step arrive in a fixed order, which maps them to bench.py's labels.
+HBM bytes follow the gfx950 rule: FETCH_SIZE and WRITE_SIZE are in KiB, FETCH_SIZE counts half the
+bytes of wide coalesced reads, so bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import OrderedDict, defaultdict
+
+STEP = ["gp_terms_kernel", "gp_block_scan_kernel", "gp_finish_kernel",
+        "ntt_pass_kernel/intt20/p0", "ntt_pass_kernel/intt20/p1", "ntt_final_kernel/intt20",
+        "ntt_pass_kernel/ntt22lde/p0", "ntt_pass_kernel/ntt22lde/p1", "ntt_final_kernel/ntt22lde",
+        "gate_constraint_kernel", "perm_constraint_kernel"]
+
+
+def short(name):
+    return name.split("(")[0].replace("plk::", "")
+
+
+def labelled(rows, name_key):
+    """yield (label, row) for the dispatches that belong to round-2+3 steps, in order."""
+    rows = [r for r in rows if r[name_key].startswith("plk::") and "table_kernel" not in r[name_key]]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    i = 0
+    for r in rows:
+        want = STEP[i % len(STEP)]
+        assert short(r[name_key]) == want.split("/")[0], (short(r[name_key]), want)
+        yield want, r
+        i += 1
+
+
+def main():
+    src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+    os.makedirs(dst, exist_ok=True)
+    stats = glob.glob(os.path.join(src, "trace", "**", "*_kernel_stats.csv"), recursive=True)[0]
+    shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
+    trace = glob.glob(os.path.join(src, "trace", "**", "*_kernel_trace.csv"), recursive=True)[0]
+    agg = OrderedDict((l, defaultdict(float)) for l in STEP)
+    info = {}
+    for label, r in labelled(list(csv.DictReader(open(trace))), "Kernel_Name"):
+        a = agg[label]
+        a["launches"] += 1
+        a["dur_ns"] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        info[label] = {"grid": f'{r["Grid_Size_X"]}x{r["Grid_Size_Y"]}', "wg": r["Workgroup_Size_X"], "vgpr": r["VGPR_Count"],
+                       "sgpr": r["SGPR_Count"], "lds": r["LDS_Block_Size"], "scratch": r["Scratch_Size"]}
+    counters = defaultdict(lambda: defaultdict(float))
+    ncount = defaultdict(lambda: defaultdict(int))
+    for path in glob.glob(os.path.join(src, "pmc_*", "**", "*_counter_collection.csv"), recursive=True):
+        rows = list(csv.DictReader(open(path)))
+        names = sorted(set(r["Counter_Name"] for r in rows))
+        for cname in names:
+            sub = [r for r in rows if r["Counter_Name"] == cname]
+            for label, r in labelled(sub, "Kernel_Name"):
+                counters[label][cname] += float(r["Counter_Value"])
+                ncount[label][cname] += 1
+    out, pmc = [], {}
+    for label in STEP:
+        a = agg[label]
+        if not a["launches"]:
+            continue
+        c = {k: v / ncount[label][k] for k, v in counters[label].items()}
+        rec = {"label": label, "launches": int(a["launches"]), "avg_ms": a["dur_ns"] / a["launches"] / 1e6, **info[label]}
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            rec["hbm_read_bytes"] = 2 * c["FETCH_SIZE"] * 1024
+            rec["hbm_write_bytes"] = c["WRITE_SIZE"] * 1024
+            rec["hbm_bytes_per_launch"] = rec["hbm_read_bytes"] + rec["hbm_write_bytes"]
+            rec["hbm_GBps"] = rec["hbm_bytes_per_launch"] / (rec["avg_ms"] * 1e-3) / 1e9
+            pmc[label] = {"hbm_bytes_per_launch": rec["hbm_bytes_per_launch"], "fetch_kib_raw": c["FETCH_SIZE"],
+                          "write_kib_raw": c["WRITE_SIZE"]}
+        if "SQ_BUSY_CYCLES" in c and "SQ_ACTIVE_INST_VALU" in c:
+            # SQ_* cycle counters are summed over shader engines / counted in quad-cycles: report ratios only
+            rec["valu_active_over_wave_cycles"] = c["SQ_ACTIVE_INST_VALU"] / max(c.get("SQ_WAVE_CYCLES", 0), 1)
+            rec["wait_any_over_wave_cycles"] = c.get("SQ_WAIT_ANY", 0) / max(c.get("SQ_WAVE_CYCLES", 0), 1)
+            rec["wait_inst_any_over_wave_cycles"] = c.get("SQ_WAIT_INST_ANY", 0) / max(c.get("SQ_WAVE_CYCLES", 0), 1)
+            rec["valu_insts_per_wave"] = c.get("SQ_INSTS_VALU", 0) / max(c.get("SQ_WAVES", 0), 1)
+            rec["waves"] = c.get("SQ_WAVES", 0)
+        for k in ("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "GRBM_GUI_ACTIVE", "SQ_ACTIVE_INST_LDS"):
+            if k in c:
+                rec[k] = c[k]
+        if "GRBM_GUI_ACTIVE" in c:
+            rec["eff_clock_GHz"] = c["GRBM_GUI_ACTIVE"] / 8 / (rec["avg_ms"] * 1e6)
+        rec["raw_counters"] = c
+        out.append(rec)
+    json.dump(out, open(os.path.join(dst, f"{tag}_by_label.json"), "w"), indent=1)
+    json.dump(pmc, open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w"), indent=1)
+    with open(os.path.join(dst, f"{tag}_by_label.md"), "w") as f:
+        f.write(f"# rocprofv3 summary `{tag}` — `python3 bench.py --steps 3 --warmup 1` (n = 2^20, N = 2^22, 18 columns)\n\n")
+        f.write("| label | launches | avg ms | grid | VGPR | LDS B | HBM GB/launch (PMC) | HBM GB/s | VALU-active / wave-cycles | wait-any / wave-cycles | eff. clock GHz |\n|---|---|---|---|---|---|---|---|---|---|---|\n")
+        for r in out:
+            f.write(f'| {r["label"]} | {r["launches"]} | {r["avg_ms"]:.3f} | {r["grid"]} | {r["vgpr"]} | {r["lds"]} | '
+                    f'{r.get("hbm_bytes_per_launch", 0) / 1e9:.3f} | {r.get("hbm_GBps", 0):.0f} | '
+                    f'{r.get("valu_active_over_wave_cycles", 0):.3f} | {r.get("wait_any_over_wave_cycles", 0):.3f} | {r.get("eff_clock_GHz", 0):.2f} |\n')
+        f.write("\nHBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950: FETCH_SIZE counts half of a wide coalesced read).\n")
+    print(open(os.path.join(dst, f"{tag}_by_label.md")).read())
+
+
+if __name__ == "__main__":
+    main()
