@@ -33,7 +33,7 @@ struct NttPlan {
   int npass = 1;
   int log_r[3] = {0, 0, 0};
   NttTables tab{};
-  DevBuf master, hi, hi_scaled, lo, scale;
+  DevBuf master, hi, hi_scaled, lo, scale, from_u64, full[2];
 };
 
 }  // namespace
@@ -137,11 +137,11 @@ Fe root_of_unity(int log_n) {
 }
 
 int alloc_table(plk_ctx* ctx, DevBuf& buf, uint64_t count, const Fe& base, int shift, const Fe& mul, hipStream_t s) {
-  HIP_TRY(ctx, hipMalloc(&buf.p, count * ELEM));
-  buf.cap = count * ELEM;
+  HIP_TRY(ctx, hipMalloc(&buf.p, count * TW_WORDS * 4));
+  buf.cap = count * TW_WORDS * 4;
   const unsigned threads = 256;
   const unsigned blocks = (unsigned)((count + threads - 1) / threads);
-  hipLaunchKernelGGL(ntt_table_kernel, dim3(blocks), dim3(threads), 0, s, (uint64_t*)buf.p, count, base, shift, mul);
+  hipLaunchKernelGGL(ntt_table_kernel, dim3(blocks), dim3(threads), 0, s, (uint32_t*)buf.p, count, base, shift, mul);
   HIP_TRY(ctx, hipGetLastError());
   return PLK_OK;
 }
@@ -165,9 +165,21 @@ int get_plan(plk_ctx* ctx, int log_n, bool inverse, hipStream_t s, NttPlan** out
   const int lo_bits = log_n / 2;
   if ((rc = alloc_table(ctx, plan.lo, 1ull << lo_bits, w, 0, one, s))) return rc;
   if ((rc = alloc_table(ctx, plan.hi, 1ull << (log_n - lo_bits), w, lo_bits, one, s))) return rc;
-  plan.tab.master = (const uint64_t*)plan.master.p;
-  plan.tab.tw_lo = (const uint64_t*)plan.lo.p;
-  plan.tab.tw_hi = (const uint64_t*)plan.hi.p;
+  plan.tab.master = (const uint32_t*)plan.master.p;
+  plan.tab.tw_lo = (const uint32_t*)plan.lo.p;
+  plan.tab.tw_hi = (const uint32_t*)plan.hi.p;
+  {
+    // 2^(256+261) mod p as a plain integer: multiplying a raw integer x by it (mont29) gives x * 2^256
+    Fe c = fe_one();
+    for (int i = 0; i < 261; ++i) c = fe_double(c);
+    const F9 c9 = f9_from_fe(c);
+    uint32_t rec[TW_WORDS] = {0};
+    for (int i = 0; i < 9; ++i) rec[i] = c9.l[i];
+    HIP_TRY(ctx, hipMalloc(&plan.from_u64.p, sizeof rec));
+    plan.from_u64.cap = sizeof rec;
+    HIP_TRY(ctx, hipMemcpy(plan.from_u64.p, rec, sizeof rec, hipMemcpyHostToDevice));
+    plan.tab.from_u64 = (const uint32_t*)plan.from_u64.p;
+  }
   plan.tab.tw_hi_scaled = plan.tab.tw_hi;
   plan.tab.scale = nullptr;
   plan.tab.lo_bits = lo_bits;
@@ -175,10 +187,31 @@ int get_plan(plk_ctx* ctx, int log_n, bool inverse, hipStream_t s, NttPlan** out
     const Fe n_inv = fe_inverse(fe_from_u64(1ull << log_n));
     if (plan.npass == 1) {
       if ((rc = alloc_table(ctx, plan.scale, 1, one, 0, n_inv, s))) return rc;
-      plan.tab.scale = (const uint64_t*)plan.scale.p;
+      plan.tab.scale = (const uint32_t*)plan.scale.p;
     } else {
       if ((rc = alloc_table(ctx, plan.hi_scaled, 1ull << (log_n - lo_bits), w, lo_bits, n_inv, s))) return rc;
-      plan.tab.tw_hi_scaled = (const uint64_t*)plan.hi_scaled.p;
+      plan.tab.tw_hi_scaled = (const uint32_t*)plan.hi_scaled.p;
+    }
+  }
+  // full inter-pass tables while they stay modest (2^25 records = 1.5 GiB); two-level beyond that
+  plan.tab.tw_full[0] = plan.tab.tw_full[1] = nullptr;
+  {
+    int log_rest = log_n;   // log2 of the sub-problem the pass works on
+    for (int pidx = 0; pidx + 1 < plan.npass; ++pidx) {
+      const int lr = plan.log_r[pidx], log_inner = log_rest - lr;
+      if (log_rest <= 25) {
+        Fe wp = w;   // omega_{N'} = omega_N^(N / N')
+        for (int i = 0; i < log_n - log_rest; ++i) wp = fe_sqr(wp);
+        const uint64_t count = 1ull << log_rest;
+        HIP_TRY(ctx, hipMalloc(&plan.full[pidx].p, count * TW_WORDS * 4));
+        plan.full[pidx].cap = count * TW_WORDS * 4;
+        const Fe mul = (inverse && pidx == 0) ? fe_inverse(fe_from_u64(1ull << log_n)) : one;
+        hipLaunchKernelGGL(ntt_full_table_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s,
+                           (uint32_t*)plan.full[pidx].p, lr, log_inner, wp, mul);
+        HIP_TRY(ctx, hipGetLastError());
+        plan.tab.tw_full[pidx] = (const uint32_t*)plan.full[pidx].p;
+      }
+      log_rest = log_inner;
     }
   }
   // tables may be used from another stream than the one that built them
@@ -211,7 +244,7 @@ int launch_ntt(plk_ctx* ctx, hipStream_t s, const uint64_t* const* in, const uin
     if ((rc = ws_get(ctx, tmp_slot, batch * N * ELEM, &p))) return rc;
     tmp = (uint64_t*)p;
   }
-  const size_t lds_bytes = 2 * NTT_TILE * sizeof(uint4);
+  const size_t lds_bytes = NTT_LDS_BYTES;
   const int P = plan->npass;
   // algorithmic bytes of the whole transform group (read the inputs once, write the outputs once),
   // attributed in equal shares to its P launches
@@ -231,6 +264,7 @@ int launch_ntt(plk_ctx* ctx, hipStream_t s, const uint64_t* const* in, const uin
     a.log_c = std::min(NTT_TILE_LOG - lr, log_inner);
     a.first = p == 0;
     a.use_scaled = p == 0;
+    a.pass = p;
     for (size_t b = 0; b < batch; ++b) {
       a.batch.in[b] = p == 0 ? src.in[b] : tmp + b * N * 4;
       a.batch.kind[b] = src.kind[b];
@@ -481,6 +515,8 @@ int plk_ctx_create(int device, plk_ctx** out) {
   CTX_TRY(hipMalloc((void**)&ctx->status_dev, sizeof(GpStatus)));
   CTX_TRY(hipHostMalloc((void**)&ctx->status_host, sizeof(GpStatus)));
   CTX_TRY(hipMemset(ctx->status_dev, 0xff, sizeof(GpStatus)));
+  CTX_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES));
+  CTX_TRY(hipFuncSetAttribute((const void*)ntt_final_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES));
 #undef CTX_TRY
   *out = ctx;
   return PLK_OK;
@@ -493,7 +529,7 @@ void plk_ctx_destroy(plk_ctx* ctx) {
   (void)hipDeviceSynchronize();
   for (auto& kv : ctx->plans) {
     NttPlan& p = kv.second;
-    for (DevBuf* b : {&p.master, &p.hi, &p.hi_scaled, &p.lo, &p.scale}) if (b->p) (void)hipFree(b->p);
+    for (DevBuf* b : {&p.master, &p.hi, &p.hi_scaled, &p.lo, &p.scale, &p.from_u64, &p.full[0], &p.full[1]}) if (b->p) (void)hipFree(b->p);
   }
   for (auto& kv : ctx->ws) if (kv.second.p) (void)hipFree(kv.second.p);
   for (auto& r : ctx->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }

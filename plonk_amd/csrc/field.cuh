@@ -133,7 +133,7 @@ __host__ __device__ inline Fe fe_pow_u64(Fe base, uint64_t e) {
   return acc;
 }
 
-// a^(p-2): Fermat inversion (a != 0). 255 squarings; used once per grand product.
+// a^(p-2): Fermat inversion (a != 0), 255 squarings.  Host-side table construction only.
 __host__ __device__ inline Fe fe_inverse(const Fe& a) {
   // exponent p - 2, scanned from the top bit
   uint32_t e[8], borrow = 2;
@@ -144,6 +144,44 @@ __host__ __device__ inline Fe fe_inverse(const Fe& a) {
     if ((e[i >> 5] >> (i & 31)) & 1) acc = fe_mul(acc, a);
   }
   return acc;
+}
+
+// Inverse by the binary extended Euclidean algorithm on the Montgomery residue (a = xR -> x^-1 R).
+// About 7x fewer instructions than the Fermat chain when a single lane has to do it, which is
+// the case for the one inversion of the grand product.  Returns zero for zero.
+__host__ __device__ inline Fe fe_inverse_eea(const Fe& a) {
+  if (fe_is_zero(a)) return a;
+  auto is_one = [](const uint32_t* x) {
+    uint32_t o = x[0] ^ 1u;
+    for (int i = 1; i < 8; ++i) o |= x[i];
+    return o == 0;
+  };
+  auto halve = [](uint32_t* x) {
+    for (int i = 0; i < 7; ++i) x[i] = (x[i] >> 1) | (x[i + 1] << 31);
+    x[7] >>= 1;
+  };
+  auto add_p = [](uint32_t* x) {   // x < p, so x + p < 2^256
+    uint32_t c = 0, ci;
+    for (int i = 0; i < 8; ++i) { x[i] = __builtin_addc(x[i], Field::P[i], c, &ci); c = ci; }
+  };
+  auto geq = [](const uint32_t* x, const uint32_t* y) {
+    for (int i = 7; i >= 0; --i) if (x[i] != y[i]) return x[i] > y[i];
+    return true;
+  };
+  auto sub_raw = [](uint32_t* x, const uint32_t* y) {
+    uint32_t b = 0, bi;
+    for (int i = 0; i < 8; ++i) { x[i] = __builtin_subc(x[i], y[i], b, &bi); b = bi; }
+  };
+  uint32_t u[8], v[8];
+  Fe b = fe_r2(), c = fe_zero();
+  for (int i = 0; i < 8; ++i) { u[i] = a.l[i]; v[i] = Field::P[i]; }
+  while (!is_one(u) && !is_one(v)) {
+    while (!(u[0] & 1)) { halve(u); if (b.l[0] & 1) add_p(b.l); halve(b.l); }
+    while (!(v[0] & 1)) { halve(v); if (c.l[0] & 1) add_p(c.l); halve(c.l); }
+    if (geq(u, v)) { sub_raw(u, v); b = fe_sub(b, c); }
+    else           { sub_raw(v, u); c = fe_sub(c, b); }
+  }
+  return is_one(u) ? b : c;
 }
 
 // ---- global / LDS access helpers: an element is two 16-byte halves

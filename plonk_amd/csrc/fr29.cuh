@@ -1,0 +1,188 @@
+// Redundant 9 x 29-bit-limb arithmetic for the transform kernels.
+//
+// Why a second representation: on MI355X v_mad_u64_u32 (32x32+64 -> 64) issues at the same
+// rate as every carry-propagating add (v_add_co / v_addc_co), so with full 32-bit limbs half of
+// a Montgomery product's instructions are carry handling.  With 29-bit limbs a whole column of
+// partial products (up to 9 of a*b plus 8 of m*p) accumulates in one 64-bit register through
+// chained multiply-adds with no carries at all: 153 multiply-adds + ~50 shifts/masks per
+// product instead of ~120 multiply-adds + ~270 adds/moves.
+//
+// Conventions
+//  * F9 = 9 limbs, value = sum l[i] * 2^(29 i).  "Normalised": l[0..7] < 2^29, l[8] holds the rest.
+//    "Lazy": limbs may exceed 29 bits (bounds below), value may exceed p.
+//  * Montgomery radix here is R' = 2^261.  mont29(a, w') with w' = w * 2^261 mod p returns
+//    a * w mod p (times nothing): data stays in the library-wide R = 2^256 Montgomery form and
+//    only the constants (twiddles) carry R'.
+//  * mont29 input bounds: a lazy with limbs < 1.3 * 2^31 and value < 64 p; b normalised, < 1.5 p.
+//    Output: normalised, value < (V_a / 70 + 1) p.
+//  * Butterfly (decimation in time): T = mont29(Y, w); X' = X + T; Y' = X - T + Q2, Q2 = 2p written
+//    with limbs in [2^29 - 1, 2^30) so the limb-wise subtraction never borrows.
+#pragma once
+#include "field.cuh"
+
+namespace plk {
+
+struct F9 { uint32_t l[9]; };
+
+constexpr uint32_t M29 = (1u << 29) - 1;
+
+namespace f9c {
+// bits [29 i, 29 i + 29) of k * p  (k * p < 2^261)
+constexpr uint32_t kp_limb29(int k, int i) {
+  // k * p as 9 x 32-bit words
+  uint32_t w[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t c = 0;
+  for (int j = 0; j < 8; ++j) { c += (uint64_t)Field::P[j] * (uint32_t)k; w[j] = (uint32_t)c; c >>= 32; }
+  w[8] = (uint32_t)c;
+  const int bit = 29 * i, wi = bit >> 5, o = bit & 31;
+  uint64_t v = (uint64_t)w[wi] >> o;
+  if (wi + 1 < 9) v |= (uint64_t)w[wi + 1] << (32 - o);
+  return (uint32_t)(i == 8 ? v : (v & M29));
+}
+constexpr uint32_t kp_word32(int k, int j) {
+  uint64_t c = 0; uint32_t w = 0;
+  for (int t = 0; t <= j && t < 8; ++t) { c += (uint64_t)Field::P[t] * (uint32_t)k; w = (uint32_t)c; c >>= 32; }
+  return j < 8 ? w : (uint32_t)c;
+}
+// 2p with every low limb raised by 2^29 and the borrow taken from the limb above
+constexpr uint32_t q2_limb(int i) {
+  return i == 0 ? kp_limb29(2, 0) + (1u << 29) : (i < 8 ? kp_limb29(2, i) + (1u << 29) - 1 : kp_limb29(2, 8) - 1);
+}
+}  // namespace f9c
+
+// ---- conversions -------------------------------------------------------------------------
+
+// 8 x 32-bit words (any value < 2^256) -> normalised F9
+__host__ __device__ __forceinline__ F9 f9_from_fe(const Fe& a) {
+  F9 r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const int bit = 29 * i, w = bit >> 5, o = bit & 31;
+    uint32_t v = a.l[w] >> o;
+    if (o > 3 && w + 1 < 8) v |= a.l[w + 1] << (32 - o);
+    r.l[i] = i == 8 ? v : (v & M29);
+  }
+  return r;
+}
+
+// carry propagation: limbs 0..7 below 2^29, limb 8 takes the rest (value unchanged)
+__host__ __device__ __forceinline__ void f9_normalize(F9& a) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { a.l[i + 1] += a.l[i] >> 29; a.l[i] &= M29; }
+}
+
+// normalised F9 with value < 2^256 -> 8 x 32-bit words (no reduction)
+__host__ __device__ __forceinline__ Fe fe_pack_f9(const F9& a) {
+  Fe r;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) {
+    const int bit = 32 * w, i = bit / 29, o = bit % 29;   // word w starts inside limb i at offset o
+    uint32_t v = a.l[i] >> o;
+    v |= a.l[i + 1] << (29 - o);
+    if (29 - o + 29 < 32 && i + 2 < 9) v |= a.l[i + 2] << (58 - o);
+    r.l[w] = v;
+  }
+  return r;
+}
+
+// lazy F9 with value < 32 p -> canonical element in [0, p) as 8 x 32-bit words
+__host__ __device__ __forceinline__ Fe fe_reduce_f9(F9 a) {
+  f9_normalize(a);
+  // 261-bit value as 9 x 32-bit words
+  uint32_t w[9];
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {
+    const int bit = 32 * j, i = bit / 29, o = bit % 29;
+    uint32_t v = a.l[i] >> o;
+    if (i + 1 < 9) v |= a.l[i + 1] << (29 - o);
+    if (29 - o + 29 < 32 && i + 2 < 9) v |= a.l[i + 2] << (58 - o);
+    w[j] = v;
+  }
+  // conditional subtraction of 16p, 8p, 4p, 2p, p
+#pragma unroll
+  for (int k = 16; k >= 1; k >>= 1) {
+    uint32_t d[9], bo = 0, bi;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) { d[j] = __builtin_subc(w[j], f9c::kp_word32(k, j), bo, &bi); bo = bi; }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) w[j] = bo ? w[j] : d[j];
+  }
+  Fe r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r.l[j] = w[j];
+  return r;
+}
+
+// ---- arithmetic --------------------------------------------------------------------------
+
+// a * b * 2^-261 mod p, product scanning with the reduction interleaved column by column.
+// p = 1 mod 2^29 for every field with two-adicity >= 29, hence m_k = -t_k mod 2^29 and the
+// p[0] term is the bare addition of m_k.
+__device__ __forceinline__ F9 mont29(const F9& a, const F9& b) {
+  static_assert(f9c::kp_limb29(1, 0) == 1, "modulus must be 1 mod 2^29");
+  uint64_t acc = 0;
+  uint32_t m[9];
+  F9 r;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+#pragma unroll
+    for (int i = 0; i <= k; ++i) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+    for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * f9c::kp_limb29(1, k - i);
+    m[k] = (0u - (uint32_t)acc) & M29;
+    acc += m[k];
+    acc >>= 29;
+  }
+#pragma unroll
+  for (int k = 9; k < 17; ++k) {
+#pragma unroll
+    for (int i = k - 8; i <= 8; ++i) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+    for (int i = k - 8; i <= 8; ++i) acc += (uint64_t)m[i] * f9c::kp_limb29(1, k - i);
+    r.l[k - 9] = (uint32_t)acc & M29;
+    acc >>= 29;
+  }
+  r.l[8] = (uint32_t)acc;
+  return r;
+}
+
+__device__ __forceinline__ F9 f9_add(const F9& a, const F9& b) {
+  F9 r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] + b.l[i];
+  return r;
+}
+
+// a - t + 2p, limb-wise; t normalised with value < 2p
+__device__ __forceinline__ F9 f9_sub_q2(const F9& a, const F9& t) {
+  F9 r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] + (f9c::q2_limb(i) - t.l[i]);
+  return r;
+}
+
+// ---- twiddle records: 9 limbs padded to 12 words (three 16-byte loads)
+__device__ __forceinline__ F9 f9_load_tw(const uint32_t* table, size_t idx) {
+  const uint4* p = reinterpret_cast<const uint4*>(table) + 3 * idx;
+  const uint4 a = p[0], b = p[1], c = p[2];
+  F9 r;
+  r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+  r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+  r.l[8] = c.x;
+  return r;
+}
+__device__ __forceinline__ void f9_store_tw(uint32_t* table, size_t idx, const F9& v) {
+  uint4* p = reinterpret_cast<uint4*>(table) + 3 * idx;
+  p[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+  p[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+  p[2] = make_uint4(v.l[8], 0, 0, 0);
+}
+
+// w (library Montgomery form, R = 2^256) -> twiddle record w * 2^261 mod p
+__host__ __device__ __forceinline__ F9 f9_twiddle_from_fe(Fe w) {
+#pragma unroll 1
+  for (int i = 0; i < 5; ++i) w = fe_double(w);
+  return f9_from_fe(w);
+}
+
+}  // namespace plk

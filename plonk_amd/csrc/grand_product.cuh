@@ -116,7 +116,7 @@ __global__ __launch_bounds__(GP_SCAN_THREADS) void gp_block_scan_kernel(uint64_t
   Fe tot_n, tot_d;
   const Fe inc_n = block_scan_mul<GP_SCAN_THREADS, false>(pn, lds, &tot_n);
   const Fe inc_d = block_scan_mul<GP_SCAN_THREADS, true>(pd, lds, &tot_d);
-  if (threadIdx.x == 0) inv_total = fe_inverse(tot_d);   // zero stays zero; the status word carries the error
+  if (threadIdx.x == 0) inv_total = fe_inverse_eea(tot_d);   // zero stays zero; the status word carries the error
   __syncthreads();
   // exclusive carries of this thread's chunk: inclusive result with the own chunk divided out is
   // not available (no division), so rebuild them from the neighbours' inclusive values

@@ -13,16 +13,25 @@
 // omega_{N'}^(k_p * lower digits) and writes digit k_p back where n_p was; the last pass reads
 // whole contiguous rows and scatters them to natural order in runs of C consecutive outputs.
 // Every global access of a tile is therefore a run of C * 32 contiguous bytes.
+//
+// Arithmetic inside a tile is the redundant 9 x 29-bit form of fr29.cuh: rows are written to
+// LDS in bit-reversed order and combined by decimation-in-time butterflies
+// (T = Y * w; X' = X + T; Y' = X - T + 2p) whose sums are left unreduced; limbs are
+// renormalised every second stage and values reduced only when a pass stores its result.
+// Between passes elements are 32-byte integers below 2^256 that may exceed p by < p/2.
 #pragma once
 #include "field.cuh"
+#include "fr29.cuh"
 
 namespace plk {
 
-constexpr int NTT_TILE_LOG = 11;            // elements per workgroup tile (2^11 * 32 B = 64 KiB LDS)
+constexpr int NTT_TILE_LOG = 11;            // elements per workgroup tile
 constexpr int NTT_TILE = 1 << NTT_TILE_LOG;
 constexpr int NTT_THREADS = 512;
 constexpr int NTT_MAX_BATCH = 24;           // columns per launch
 constexpr int NTT_MASTER_LOG = 11;          // per-tile twiddles: omega_{2^11}^e, e < 2^10
+constexpr size_t NTT_LDS_BYTES = (size_t)NTT_TILE * 36;   // 9 words per element
+constexpr int TW_WORDS = 12;                // one twiddle record (9 limbs + padding)
 
 enum NttInputKind : uint32_t { NTT_IN_FIELD = 0, NTT_IN_U64 = 1 };
 
@@ -32,59 +41,93 @@ struct NttBatch {
   uint32_t kind[NTT_MAX_BATCH];   // NttInputKind, honoured by the first pass only
 };
 
-// Device-resident constants of one (log N, direction) transform.
+// Device-resident constants of one (log N, direction) transform; every table holds twiddle
+// records (value * 2^261 mod p as 9 limbs, fr29.cuh).
 struct NttTables {
-  const uint64_t* master;  // omega_{2^11}^e (or its inverse), e < 2^10
-  const uint64_t* tw_hi;   // omega_N^(e << lo_bits), e < 2^(logN - lo_bits)
-  const uint64_t* tw_hi_scaled;  // same times 1/N (inverse, first inter-pass twiddle); == tw_hi for forward
-  const uint64_t* tw_lo;   // omega_N^e, e < 2^lo_bits
-  const uint64_t* scale;   // 1/N as one element, or nullptr
+  const uint32_t* master;  // omega_{2^11}^e (or its inverse), e < 2^10
+  const uint32_t* tw_hi;   // omega_N^(e << lo_bits), e < 2^(logN - lo_bits)
+  const uint32_t* tw_hi_scaled;  // same times 1/N (inverse, first inter-pass twiddle); == tw_hi for forward
+  const uint32_t* tw_lo;   // omega_N^e, e < 2^lo_bits
+  const uint32_t* scale;   // 1/N as one record, or nullptr
+  const uint32_t* from_u64;  // 2^(256+261) mod p: raw integer -> element, one record
+  // full inter-pass tables (nullptr = use the two-level pair above): after pass p,
+  // record[(k << log_inner) + q] = omega_{N'}^(k q), times 1/N in pass 0 of an inverse transform
+  const uint32_t* tw_full[2];
   int lo_bits;
 };
 
 __device__ __forceinline__ uint32_t bitrev(uint32_t x, int bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
 
-// LDS tile: element e -> low half at lds[e], high half at lds[NTT_TILE + e]
-__device__ __forceinline__ Fe lds_get(const uint4* lds, int e) {
-  const uint4 lo = lds[e], hi = lds[NTT_TILE + e];
-  Fe r;
-  r.l[0] = lo.x; r.l[1] = lo.y; r.l[2] = lo.z; r.l[3] = lo.w;
-  r.l[4] = hi.x; r.l[5] = hi.y; r.l[6] = hi.z; r.l[7] = hi.w;
-  return r;
-}
-__device__ __forceinline__ void lds_put(uint4* lds, int e, const Fe& v) {
-  lds[e] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
-  lds[NTT_TILE + e] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+// LDS tile: element e -> limbs 0-3 at A[e], limbs 4-7 at B[e] (16 bytes each), limb 8 at C[e]
+struct Tile {
+  uint4* A; uint4* B; uint32_t* C;
+  __device__ __forceinline__ explicit Tile(void* base)
+      : A(reinterpret_cast<uint4*>(base)), B(A + NTT_TILE), C(reinterpret_cast<uint32_t*>(B + NTT_TILE)) {}
+  __device__ __forceinline__ F9 get(int e) const {
+    const uint4 a = A[e], b = B[e];
+    F9 r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    r.l[8] = C[e];
+    return r;
+  }
+  __device__ __forceinline__ void put(int e, const F9& v) const {
+    A[e] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    B[e] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+    C[e] = v.l[8];
+  }
+};
+
+// One input element -> normalised F9 (value < 1.5 p).
+__device__ __forceinline__ F9 load_input(const uint64_t* in, uint64_t idx, bool valid, uint32_t kind, const uint32_t* from_u64) {
+  F9 v;
+  if (!valid) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) v.l[i] = 0;
+  } else if (kind == NTT_IN_U64) {
+    const uint64_t x = in[idx];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) v.l[i] = 0;
+    v.l[0] = (uint32_t)x & M29; v.l[1] = (uint32_t)(x >> 29) & M29; v.l[2] = (uint32_t)(x >> 58);
+    v = mont29(v, f9_load_tw(from_u64, 0));   // F::from(u64)
+  } else {
+    v = f9_from_fe(fe_load(in, idx));
+  }
+  return v;
 }
 
-// In-LDS decimation-in-frequency transform of size 2^log_r along the row axis of a
-// [2^log_r][2^log_c] tile.  Leaves row i holding output digit bitrev(i).
-__device__ __forceinline__ void tile_dif(uint4* lds, int log_r, int log_c, const uint64_t* master) {
+// In-LDS decimation-in-time transform of size 2^log_r along the row axis of a
+// [2^log_r][2^log_c] tile whose rows were stored in bit-reversed order; leaves natural order.
+// Outputs are lazy: limbs < 1.5 * 2^30, value < (2 + 2 log_r) p.
+__device__ __forceinline__ void tile_dit(const Tile& t, int log_r, int log_c, const uint32_t* master) {
   const int total = 1 << (log_r + log_c - 1);  // butterflies per stage
-  for (int lh = log_r - 1; lh >= 0; --lh) {
+  for (int lh = 0; lh < log_r; ++lh) {
     const int h = 1 << lh;
+    const bool renorm = (lh & 1) != 0;         // after every second stage
     for (int b = threadIdx.x; b < total; b += NTT_THREADS) {
       const int c = b & ((1 << log_c) - 1);
-      const int t = b >> log_c;
-      const int j = t & (h - 1);
-      const int i0 = ((t >> lh) << (lh + 1)) + j;
+      const int q = b >> log_c;
+      const int j = q & (h - 1);
+      const int i0 = ((q >> lh) << (lh + 1)) + j;
       const int e0 = (i0 << log_c) + c, e1 = ((i0 + h) << log_c) + c;
-      const Fe x = lds_get(lds, e0), y = lds_get(lds, e1);
-      lds_put(lds, e0, fe_add(x, y));
-      Fe d = fe_sub(x, y);
-      if (lh > 0 && j != 0) d = fe_mul(d, fe_load(master, (size_t)j << (NTT_MASTER_LOG - 1 - lh)));
-      lds_put(lds, e1, d);
+      const F9 x = t.get(e0);
+      F9 y = t.get(e1);
+      if (lh > 0) y = mont29(y, f9_load_tw(master, (size_t)j << (NTT_MASTER_LOG - 1 - lh)));
+      F9 u = f9_add(x, y), v = f9_sub_q2(x, y);
+      if (renorm) { f9_normalize(u); f9_normalize(v); }
+      t.put(e0, u);
+      t.put(e1, v);
     }
     __syncthreads();
   }
 }
 
-// omega_N^E from the two-level table
-__device__ __forceinline__ Fe twiddle_two_level(const uint64_t* hi, const uint64_t* lo, int lo_bits, uint64_t E) {
-  const Fe a = fe_load(hi, E >> lo_bits);
+// omega_N^E (twiddle record) from the two-level table
+__device__ __forceinline__ F9 twiddle_two_level(const uint32_t* hi, const uint32_t* lo, int lo_bits, uint64_t E) {
+  const F9 a = f9_load_tw(hi, E >> lo_bits);
   const uint64_t el = E & ((1ull << lo_bits) - 1);
   if (el == 0) return a;
-  return fe_mul(a, fe_load(lo, el));
+  return mont29(a, f9_load_tw(lo, el));
 }
 
 struct NttPassArgs {
@@ -97,11 +140,13 @@ struct NttPassArgs {
   int log_c;         // columns per tile
   int first;         // 1 = reads the caller's input (kinds, zero padding)
   int use_scaled;    // 1 = take tw_hi_scaled for the inter-pass twiddle
+  int pass;          // index of this pass (selects tw_full)
 };
 
 // Non-final pass: digit transform + inter-pass twiddle; out may alias in when !first.
 __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const NttPassArgs a) {
-  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const Tile tile(lds_raw);
   const int poly = blockIdx.y;
   const uint64_t* __restrict__ in = a.batch.in[poly];
   uint64_t* __restrict__ out = a.batch.out[poly];
@@ -116,25 +161,24 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const NttPassArgs
   for (int e = threadIdx.x; e < elems; e += NTT_THREADS) {
     const int r = e >> log_c, c = e & ((1 << log_c) - 1);
     const uint64_t idx = base + ((uint64_t)r << log_inner) + c;
-    Fe v;
-    if (a.first && idx >= a.n_in) v = fe_zero();
-    else if (kind == NTT_IN_U64) v = fe_from_u64(in[idx]);
-    else v = fe_load(in, idx);
-    lds_put(lds, e, v);
+    const F9 v = load_input(in, idx, !(a.first && idx >= a.n_in), kind, a.tab.from_u64);
+    tile.put((int)(bitrev((uint32_t)r, log_r) << log_c) + c, v);
   }
   __syncthreads();
-  tile_dif(lds, log_r, log_c, a.tab.master);
+  tile_dit(tile, log_r, log_c, a.tab.master);
 
   // inter-pass twiddle omega_{N'}^(k * q), N' = 2^(log_r + log_inner), as a power of omega_N
   const int shift = a.log_n - (log_r + log_inner);
-  const uint64_t* hi = a.use_scaled ? a.tab.tw_hi_scaled : a.tab.tw_hi;
+  const uint32_t* hi = a.use_scaled ? a.tab.tw_hi_scaled : a.tab.tw_hi;
+  const uint32_t* full = a.tab.tw_full[a.pass];
   for (int e = threadIdx.x; e < elems; e += NTT_THREADS) {
-    const int r = e >> log_c, c = e & ((1 << log_c) - 1);
-    const uint32_t k = bitrev((uint32_t)r, log_r);
+    const int k = e >> log_c, c = e & ((1 << log_c) - 1);
     const uint64_t q = q0 + c;
-    Fe v = lds_get(lds, e);
-    v = fe_mul(v, twiddle_two_level(hi, a.tab.tw_lo, a.tab.lo_bits, ((uint64_t)k * q) << shift));
-    fe_store(out, base + ((uint64_t)k << log_inner) + c, v);
+    F9 v = tile.get(e);
+    const F9 tw = full ? f9_load_tw(full, ((uint64_t)k << log_inner) + q)
+                       : twiddle_two_level(hi, a.tab.tw_lo, a.tab.lo_bits, ((uint64_t)k * q) << shift);
+    v = mont29(v, tw);
+    fe_store(out, base + ((uint64_t)k << log_inner) + c, fe_pack_f9(v));
   }
 }
 
@@ -150,9 +194,10 @@ struct NttFinalArgs {
   int first;
 };
 
-// Last pass: contiguous rows in, natural-order scatter out (never in place).
+// Last pass: contiguous rows in, natural-order scatter out (never in place), canonical values.
 __global__ __launch_bounds__(NTT_THREADS) void ntt_final_kernel(const NttFinalArgs a) {
-  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const Tile tile(lds_raw);
   const int poly = blockIdx.y;
   const uint64_t* __restrict__ in = a.batch.in[poly];
   uint64_t* __restrict__ out = a.batch.out[poly];
@@ -162,42 +207,48 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_final_kernel(const NttFinalAr
   const int elems = 1 << (log_r + log_c);
   const uint32_t kind = a.first ? a.batch.kind[poly] : (uint32_t)NTT_IN_FIELD;
 
-  // tile[r][c] <- row o_c = (k1_0 + c) * R2 + k2, element r.  Threads run along r so that
+  // tile[bitrev(r)][c] <- row o_c = (k1_0 + c) * R2 + k2, element r.  Threads run along r so that
   // each row is read as one contiguous stream.
   for (int e = threadIdx.x; e < elems; e += NTT_THREADS) {
     const int r = e & ((1 << log_r) - 1), c = e >> log_r;
     const uint64_t orow = ((k1_0 + c) << a.log_r2) + k2;
     const uint64_t idx = (orow << log_r) + r;
-    Fe v;
-    if (a.first && idx >= a.n_in) v = fe_zero();
-    else if (kind == NTT_IN_U64) v = fe_from_u64(in[idx]);
-    else v = fe_load(in, idx);
-    lds_put(lds, (r << log_c) + c, v);
+    const F9 v = load_input(in, idx, !(a.first && idx >= a.n_in), kind, a.tab.from_u64);
+    tile.put((int)(bitrev((uint32_t)r, log_r) << log_c) + c, v);
   }
   __syncthreads();
-  tile_dif(lds, log_r, log_c, a.tab.master);
+  tile_dit(tile, log_r, log_c, a.tab.master);
 
   const bool scaled = a.tab.scale != nullptr;
-  Fe sc = fe_zero();
-  if (scaled) sc = fe_load(a.tab.scale, 0);
+  F9 sc;
+  if (scaled) sc = f9_load_tw(a.tab.scale, 0);
   for (int e = threadIdx.x; e < elems; e += NTT_THREADS) {
-    const int r = e >> log_c, c = e & ((1 << log_c) - 1);
-    const uint64_t k = bitrev((uint32_t)r, log_r);
-    Fe v = lds_get(lds, e);
-    if (scaled) v = fe_mul(v, sc);
-    const uint64_t dst = (k1_0 + c) + (k2 << a.log_r1) + (k << (a.log_r1 + a.log_r2));
-    fe_store(out, dst, v);
+    const int k = e >> log_c, c = e & ((1 << log_c) - 1);
+    F9 v = tile.get(e);
+    if (scaled) v = mont29(v, sc);
+    const uint64_t dst = (k1_0 + c) + (k2 << a.log_r1) + ((uint64_t)k << (a.log_r1 + a.log_r2));
+    fe_store(out, dst, fe_reduce_f9(v));
   }
 }
 
 // ---- table construction (device side, run once per plan)
 
-// out[i] = base^(i << shift) * mul, i < count ; base, mul given as elements
-__global__ void ntt_table_kernel(uint64_t* out, uint64_t count, Fe base, int shift, Fe mul) {
+// record[i] = (base^(i << shift) * mul) as a twiddle record, i < count; base, mul in the
+// library's Montgomery form
+__global__ void ntt_table_kernel(uint32_t* out, uint64_t count, Fe base, int shift, Fe mul) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
-  Fe v = fe_mul(fe_pow_u64(base, i << shift), mul);
-  fe_store(out, i, v);
+  const Fe v = fe_mul(fe_pow_u64(base, i << shift), mul);
+  f9_store_tw(out, i, f9_twiddle_from_fe(v));
+}
+
+// record[(k << log_inner) + q] = base^(k q) * mul, k < 2^log_r, q < 2^log_inner
+__global__ void ntt_full_table_kernel(uint32_t* out, int log_r, int log_inner, Fe base, Fe mul) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >> (log_r + log_inner)) return;
+  const uint64_t k = i >> log_inner, q = i & ((1ull << log_inner) - 1);
+  const Fe v = fe_mul(fe_pow_u64(base, k * q), mul);
+  f9_store_tw(out, i, f9_twiddle_from_fe(v));
 }
 
 }  // namespace plk
