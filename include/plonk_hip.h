@@ -127,6 +127,21 @@ int plk_round23(plk_ctx* ctx, const uint64_t* const wires[PLK_NUM_WIRES], const 
 int plk_dev_ntt_batch(plk_ctx* ctx, void* stream, const uint64_t* const* in, const uint32_t* kinds, size_t batch,
                       size_t n_in, size_t N, int inverse, uint64_t* const* out);
 
+/* Same transform over `count` equally spaced columns: column b is read at in + b * in_stride and
+ * written at out + b * out_stride (strides in elements, >= n_in and >= N).  This is the shape of
+ * the row / column phases of a four-step transform on a matrix held in HBM. */
+int plk_dev_ntt_strided(plk_ctx* ctx, void* stream, const uint64_t* in, size_t in_stride, uint32_t kind, size_t count,
+                        size_t n_in, size_t N, int inverse, uint64_t* out, size_t out_stride);
+
+/* out[i] = a[i] * b[i] (field product), n elements; out may alias a or b */
+int plk_dev_mul(plk_ctx* ctx, void* stream, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out);
+
+/* out[r * cols + c] = omega_N^((row0 + r) * (col0 + c)) (omega_N^-1 if inverse), optionally times 1/N:
+ * the inter-phase twiddle block of a four-step transform of size N owned by one rank.
+ * No counterpart in the reference (ark-poly runs one shared-memory FFT). */
+int plk_dev_twiddle_block(plk_ctx* ctx, void* stream, size_t N, int inverse, int scale_by_inverse_n, size_t rows, size_t cols,
+                          size_t row0, size_t col0, uint64_t* out);
+
 int plk_dev_grand_product(plk_ctx* ctx, void* stream, const uint64_t* const wires[PLK_NUM_WIRES],
                           const uint64_t* const sigma[PLK_NUM_WIRES], size_t n,
                           const uint64_t beta[4], const uint64_t gamma[4], uint64_t* z_out);
@@ -140,6 +155,15 @@ int plk_dev_perm_constraint_eval(plk_ctx* ctx, void* stream, const uint64_t* z_e
                                  const uint64_t* const sigma_evals[PLK_NUM_WIRES],
                                  const uint64_t* const wire_evals[PLK_NUM_WIRES], size_t N,
                                  const uint64_t beta[4], const uint64_t gamma[4], size_t z_shift, uint64_t* out);
+
+/* The same loop on `count` consecutive points of the domain starting at index0 (the identity term
+ * uses index0 + i, src/permutation_polynomial.rs:351).  z_evals holds count + z_shift elements:
+ * the range followed by its next z_shift points, so no wrap-around is taken.  Used when the
+ * evaluation domain is split over GPUs. */
+int plk_dev_perm_constraint_eval_range(plk_ctx* ctx, void* stream, const uint64_t* z_evals,
+                                       const uint64_t* const sigma_evals[PLK_NUM_WIRES],
+                                       const uint64_t* const wire_evals[PLK_NUM_WIRES], size_t count, size_t index0,
+                                       const uint64_t beta[4], const uint64_t gamma[4], size_t z_shift, uint64_t* out);
 
 int plk_dev_round23(plk_ctx* ctx, void* stream, const uint64_t* const wires[PLK_NUM_WIRES],
                     const uint64_t* const sel[PLK_NUM_SELECTORS], const uint64_t* const sigma[PLK_NUM_WIRES],

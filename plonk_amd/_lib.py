@@ -51,9 +51,13 @@ SIGNATURES = {
     "plk_perm_constraints": (C.c_int, [C.c_void_p, u64p, u64pp, u64pp, C.c_size_t, C.c_size_t, u64p, u64p, C.c_size_t, u64p]),
     "plk_round23": (C.c_int, [C.c_void_p, u64pp, u64pp, u64pp, C.c_size_t, C.c_size_t, u64p, u64p, C.c_size_t, u64p, u64p, u64p]),
     "plk_dev_ntt_batch": (C.c_int, [C.c_void_p, C.c_void_p, u64pp, u32p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, u64pp]),
+    "plk_dev_ntt_strided": (C.c_int, [C.c_void_p, C.c_void_p, u64p, C.c_size_t, C.c_uint32, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, u64p, C.c_size_t]),
+    "plk_dev_mul": (C.c_int, [C.c_void_p, C.c_void_p, u64p, u64p, C.c_size_t, u64p]),
+    "plk_dev_twiddle_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, u64p]),
     "plk_dev_grand_product": (C.c_int, [C.c_void_p, C.c_void_p, u64pp, u64pp, C.c_size_t, u64p, u64p, u64p]),
     "plk_dev_gate_constraint_eval": (C.c_int, [C.c_void_p, C.c_void_p, u64pp, u64pp, C.c_size_t, u64p]),
     "plk_dev_perm_constraint_eval": (C.c_int, [C.c_void_p, C.c_void_p, u64p, u64pp, u64pp, C.c_size_t, u64p, u64p, C.c_size_t, u64p]),
+    "plk_dev_perm_constraint_eval_range": (C.c_int, [C.c_void_p, C.c_void_p, u64p, u64pp, u64pp, C.c_size_t, C.c_size_t, u64p, u64p, C.c_size_t, u64p]),
     "plk_dev_round23": (C.c_int, [C.c_void_p, C.c_void_p, u64pp, u64pp, u64pp, C.c_size_t, C.c_size_t, u64p, u64p, C.c_size_t, u64p, u64p, u64p]),
     "plk_dev_status": (C.c_int, [C.c_void_p, C.c_void_p]),
     "plk_profile_begin": (None, [C.c_void_p]),

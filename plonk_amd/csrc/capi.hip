@@ -221,27 +221,37 @@ int get_plan(plk_ctx* ctx, int log_n, bool inverse, hipStream_t s, NttPlan** out
   return PLK_OK;
 }
 
-// Enqueue `batch` (<= NTT_MAX_BATCH) transforms.
+// Enqueue `batch` transforms.  Columns are given either as pointer tables (stride_in/out == 0,
+// batch <= NTT_MAX_BATCH) or as one base pointer plus a stride in elements.
 int launch_ntt(plk_ctx* ctx, hipStream_t s, const uint64_t* const* in, const uint32_t* kinds, size_t batch,
-               size_t n_in, size_t N, bool inverse, uint64_t* const* out, const char* tmp_slot = "ntt_tmp") {
+               size_t n_in, size_t N, bool inverse, uint64_t* const* out, size_t stride_in = 0, size_t stride_out = 0) {
   int log_n, rc;
   if ((rc = check_domain(ctx, N, &log_n))) return rc;
   if (n_in > N) return fail(ctx, PLK_ERR_LENGTH, "more input elements than domain points");
   if (batch == 0) return PLK_OK;
-  if (batch > NTT_MAX_BATCH) return fail(ctx, PLK_ERR_ARG, "batch exceeds PLK_MAX_BATCH");
+  const bool ptr_tables = stride_in == 0 || stride_out == 0;
+  if (ptr_tables && batch > NTT_MAX_BATCH) return fail(ctx, PLK_ERR_ARG, "batch exceeds PLK_MAX_BATCH");
+  if (batch > 65535) return fail(ctx, PLK_ERR_ARG, "batch exceeds 65535");
   NttPlan* plan;
   if ((rc = get_plan(ctx, log_n, inverse, s, &plan))) return rc;
 
-  NttBatch src{};
-  for (size_t b = 0; b < batch; ++b) {
-    if ((!in[b] && n_in) || !out[b]) return fail(ctx, PLK_ERR_ARG, "null column pointer");
-    src.in[b] = in[b];
-    src.kind[b] = kinds ? kinds[b] : (uint32_t)NTT_IN_FIELD;
+  NttBatch user{};   // the caller's buffers
+  const size_t n_ptr_in = stride_in ? 1 : batch, n_ptr_out = stride_out ? 1 : batch;
+  for (size_t b = 0; b < n_ptr_in; ++b) {
+    if (!in[b] && n_in) return fail(ctx, PLK_ERR_ARG, "null column pointer");
+    user.in[b] = in[b];
+    user.kind[b] = kinds ? kinds[b] : (uint32_t)NTT_IN_FIELD;
   }
+  for (size_t b = 0; b < n_ptr_out; ++b) {
+    if (!out[b]) return fail(ctx, PLK_ERR_ARG, "null column pointer");
+    user.out[b] = out[b];
+  }
+  user.stride_in = stride_in * 4;
+  user.stride_out = stride_out * 4;
   uint64_t* tmp = nullptr;
   if (plan->npass > 1) {
     void* p;
-    if ((rc = ws_get(ctx, tmp_slot, batch * N * ELEM, &p))) return rc;
+    if ((rc = ws_get(ctx, "ntt_tmp", batch * N * ELEM, &p))) return rc;
     tmp = (uint64_t*)p;
   }
   const size_t lds_bytes = NTT_LDS_BYTES;
@@ -250,6 +260,10 @@ int launch_ntt(plk_ctx* ctx, hipStream_t s, const uint64_t* const* in, const uin
   // attributed in equal shares to its P launches
   const double alg_share = (32.0 * (double)n_in + 32.0 * (double)N) * (double)batch / P;
   const std::string tag = std::string(inverse ? "/intt" : "/ntt") + std::to_string(log_n) + (n_in < N ? "lde" : "");
+  auto from_user = [&](NttBatch& b) { for (int i = 0; i < NTT_MAX_BATCH; ++i) { b.in[i] = user.in[i]; b.kind[i] = user.kind[i]; } b.stride_in = user.stride_in; };
+  auto to_user = [&](NttBatch& b) { for (int i = 0; i < NTT_MAX_BATCH; ++i) b.out[i] = user.out[i]; b.stride_out = user.stride_out; };
+  auto from_tmp = [&](NttBatch& b) { b.in[0] = tmp; b.stride_in = (uint64_t)N * 4; b.kind[0] = NTT_IN_FIELD; };
+  auto to_tmp = [&](NttBatch& b) { b.out[0] = tmp; b.stride_out = (uint64_t)N * 4; };
   // non-final passes
   int log_inner = log_n;
   for (int p = 0; p + 1 < P; ++p) {
@@ -265,11 +279,8 @@ int launch_ntt(plk_ctx* ctx, hipStream_t s, const uint64_t* const* in, const uin
     a.first = p == 0;
     a.use_scaled = p == 0;
     a.pass = p;
-    for (size_t b = 0; b < batch; ++b) {
-      a.batch.in[b] = p == 0 ? src.in[b] : tmp + b * N * 4;
-      a.batch.kind[b] = src.kind[b];
-      a.batch.out[b] = tmp + b * N * 4;
-    }
+    if (p == 0) from_user(a.batch); else from_tmp(a.batch);
+    to_tmp(a.batch);
     const unsigned tiles = 1u << (log_n - lr - a.log_c);
     ProfScope ps(ctx, s, "ntt_pass_kernel" + tag + "/p" + std::to_string(p), alg_share);
     hipLaunchKernelGGL(ntt_pass_kernel, dim3(tiles, (unsigned)batch), dim3(NTT_THREADS), lds_bytes, s, a);
@@ -285,11 +296,8 @@ int launch_ntt(plk_ctx* ctx, hipStream_t s, const uint64_t* const* in, const uin
     a.log_r2 = P >= 3 ? plan->log_r[1] : 0;
     a.log_c = std::min(NTT_TILE_LOG - a.log_r, a.log_r1);
     a.first = P == 1;
-    for (size_t b = 0; b < batch; ++b) {
-      a.batch.in[b] = P == 1 ? src.in[b] : tmp + b * N * 4;
-      a.batch.kind[b] = src.kind[b];
-      a.batch.out[b] = out[b];
-    }
+    if (P == 1) from_user(a.batch); else from_tmp(a.batch);
+    to_user(a.batch);
     const unsigned tiles = 1u << (log_n - a.log_r - a.log_c);
     ProfScope ps(ctx, s, "ntt_final_kernel" + tag, alg_share);
     hipLaunchKernelGGL(ntt_final_kernel, dim3(tiles, (unsigned)batch), dim3(NTT_THREADS), lds_bytes, s, a);
@@ -367,10 +375,12 @@ int launch_gate_eval(plk_ctx* ctx, hipStream_t s, const uint64_t* const w[4], co
 }
 
 int launch_perm_eval(plk_ctx* ctx, hipStream_t s, const uint64_t* z, const uint64_t* const sg[4], const uint64_t* const w[4],
-                     size_t N, const uint64_t beta_[4], const uint64_t gamma_[4], size_t z_shift, uint64_t* out) {
+                     size_t N, const uint64_t beta_[4], const uint64_t gamma_[4], size_t z_shift, uint64_t* out,
+                     size_t index0 = 0, bool halo = false) {
   if (!out || !z || !beta_ || !gamma_) return fail(ctx, PLK_ERR_ARG, "null pointer");
   if (N == 0) return PLK_OK;
-  if (z_shift >= N) z_shift %= N;
+  if (!halo && z_shift >= N) z_shift %= N;
+  const size_t z_len = halo ? N + z_shift : N;
   const Fe beta = fe_from_limbs64(beta_), gamma = fe_from_limbs64(gamma_);
   if (!fe_is_canonical(beta) || !fe_is_canonical(gamma)) return fail(ctx, PLK_ERR_ARG, "beta/gamma not reduced mod p");
   PermCols cols{};
@@ -384,8 +394,8 @@ int launch_perm_eval(plk_ctx* ctx, hipStream_t s, const uint64_t* z, const uint6
   const unsigned blocks = (unsigned)((N + EW_THREADS - 1) / EW_THREADS);
   {
   ProfScope ps(ctx, s, "perm_constraint_kernel", 320.0 * (double)N);
-  hipLaunchKernelGGL(perm_constraint_kernel, dim3(blocks), dim3(EW_THREADS), 0, s, cols, (uint64_t)N, beta, gamma, beta_r2,
-                     (uint64_t)z_shift, out);
+  hipLaunchKernelGGL(perm_constraint_kernel, dim3(blocks), dim3(EW_THREADS), 0, s, cols, (uint64_t)N, (uint64_t)index0,
+                     (uint64_t)z_len, beta, gamma, beta_r2, (uint64_t)z_shift, out);
   }
   HIP_TRY(ctx, hipGetLastError());
   return PLK_OK;
@@ -645,6 +655,15 @@ int plk_dev_perm_constraint_eval(plk_ctx* ctx, void* stream, const uint64_t* z_e
   return launch_perm_eval(ctx, (hipStream_t)stream, z_evals, sigma_evals, wire_evals, N, beta, gamma, z_shift, out);
 }
 
+int plk_dev_perm_constraint_eval_range(plk_ctx* ctx, void* stream, const uint64_t* z_evals, const uint64_t* const sigma_evals[4],
+                                       const uint64_t* const wire_evals[4], size_t count, size_t index0, const uint64_t beta[4],
+                                       const uint64_t gamma[4], size_t z_shift, uint64_t* out) {
+  int rc = use_device(ctx);
+  if (rc) return rc;
+  if (!sigma_evals || !wire_evals) return fail(ctx, PLK_ERR_ARG, "null pointer table");
+  return launch_perm_eval(ctx, (hipStream_t)stream, z_evals, sigma_evals, wire_evals, count, beta, gamma, z_shift, out, index0, true);
+}
+
 int plk_dev_round23(plk_ctx* ctx, void* stream, const uint64_t* const wires[4], const uint64_t* const sel[9],
                     const uint64_t* const sigma[4], size_t n, size_t N, const uint64_t beta[4], const uint64_t gamma[4],
                     size_t z_shift, uint64_t* z_out, uint64_t* gate_out, uint64_t* perm_out) {
@@ -652,6 +671,53 @@ int plk_dev_round23(plk_ctx* ctx, void* stream, const uint64_t* const wires[4], 
   if (rc) return rc;
   if (!wires || !sigma) return fail(ctx, PLK_ERR_ARG, "null pointer table");
   return launch_round23(ctx, (hipStream_t)stream, wires, sel, sigma, n, N, beta, gamma, z_shift, z_out, gate_out, perm_out);
+}
+
+int plk_dev_ntt_strided(plk_ctx* ctx, void* stream, const uint64_t* in, size_t in_stride, uint32_t kind, size_t count,
+                        size_t n_in, size_t N, int inverse, uint64_t* out, size_t out_stride) {
+  int rc = use_device(ctx);
+  if (rc) return rc;
+  if (count == 0) return PLK_OK;
+  if (!out || (!in && n_in)) return fail(ctx, PLK_ERR_ARG, "null pointer");
+  if (in_stride < n_in || out_stride < N) return fail(ctx, PLK_ERR_ARG, "stride shorter than a column");
+  const uint64_t* ins[1] = {in};
+  uint64_t* outs[1] = {out};
+  const uint32_t kinds[1] = {kind};
+  for (size_t done = 0; done < count; done += 32768) {   // grid.y limit
+    const size_t m = std::min<size_t>(32768, count - done);
+    ins[0] = in + done * in_stride * 4;
+    outs[0] = out + done * out_stride * 4;
+    if ((rc = launch_ntt(ctx, (hipStream_t)stream, ins, kinds, m, n_in, N, inverse != 0, outs, in_stride, out_stride))) return rc;
+  }
+  return PLK_OK;
+}
+
+int plk_dev_mul(plk_ctx* ctx, void* stream, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
+  int rc = use_device(ctx);
+  if (rc) return rc;
+  if (n == 0) return PLK_OK;
+  if (!a || !b || !out) return fail(ctx, PLK_ERR_ARG, "null pointer");
+  hipLaunchKernelGGL(mul_kernel, dim3((unsigned)((n + EW_THREADS - 1) / EW_THREADS)), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                     a, b, (uint64_t)n, out);
+  HIP_TRY(ctx, hipGetLastError());
+  return PLK_OK;
+}
+
+int plk_dev_twiddle_block(plk_ctx* ctx, void* stream, size_t N, int inverse, int scale_by_inverse_n, size_t rows, size_t cols,
+                          size_t row0, size_t col0, uint64_t* out) {
+  int rc = use_device(ctx), log_n;
+  if (rc) return rc;
+  if ((rc = check_domain(ctx, N, &log_n))) return rc;
+  if (rows * cols == 0) return PLK_OK;
+  if (!out) return fail(ctx, PLK_ERR_ARG, "null pointer");
+  Fe w = root_of_unity(log_n);
+  if (inverse) w = fe_inverse(w);
+  const Fe mul = scale_by_inverse_n ? fe_inverse(fe_from_u64((uint64_t)N)) : fe_one();
+  const uint64_t total = (uint64_t)rows * cols;
+  hipLaunchKernelGGL(twiddle_block_kernel, dim3((unsigned)((total + EW_THREADS - 1) / EW_THREADS)), dim3(EW_THREADS), 0,
+                     (hipStream_t)stream, out, (uint64_t)rows, (uint64_t)cols, (uint64_t)row0, (uint64_t)col0, w, mul);
+  HIP_TRY(ctx, hipGetLastError());
+  return PLK_OK;
 }
 
 int plk_dev_status(plk_ctx* ctx, void* stream) {

@@ -46,13 +46,16 @@ struct PermCols {
   const uint64_t* w[4];
 };
 
-__global__ __launch_bounds__(EW_THREADS) void perm_constraint_kernel(PermCols cols, uint64_t N, Fe beta, Fe gamma, Fe beta_r2,
-                                                                     uint64_t z_shift, uint64_t* out) {
+// `count` points starting at domain index `index0`; z holds z_len elements and the neighbour
+// index wraps at z_len (z_len = N for a whole domain; count + z_shift when a halo is appended).
+__global__ __launch_bounds__(EW_THREADS) void perm_constraint_kernel(PermCols cols, uint64_t count, uint64_t index0, uint64_t z_len,
+                                                                     Fe beta, Fe gamma, Fe beta_r2, uint64_t z_shift, uint64_t* out) {
   const uint64_t i = (uint64_t)blockIdx.x * EW_THREADS + threadIdx.x;
-  if (i >= N) return;
-  uint64_t inext = i + z_shift;            // z_shift < N is checked on the host
-  if (inext >= N) inext -= N;
-  Fe iraw = fe_zero(); iraw.l[0] = (uint32_t)i; iraw.l[1] = (uint32_t)(i >> 32);
+  if (i >= count) return;
+  uint64_t inext = i + z_shift;            // z_shift < z_len is checked on the host
+  if (inext >= z_len) inext -= z_len;
+  const uint64_t gi = index0 + i;
+  Fe iraw = fe_zero(); iraw.l[0] = (uint32_t)gi; iraw.l[1] = (uint32_t)(gi >> 32);
   const Fe bi_g = fe_add(fe_mul(iraw, beta_r2), gamma);   // beta * F::from(i) + gamma  (:351)
   Fe lhs, rhs;
 #pragma unroll
@@ -79,6 +82,23 @@ __global__ __launch_bounds__(EW_THREADS) void scale_kernel(const uint64_t* in, u
   const uint64_t i = (uint64_t)blockIdx.x * EW_THREADS + threadIdx.x;
   if (i >= n) return;
   fe_store(out, i, fe_mul(fe_load(in, i), factor));
+}
+
+// out[i] = a[i] * b[i]
+__global__ __launch_bounds__(EW_THREADS) void mul_kernel(const uint64_t* a, const uint64_t* b, uint64_t n, uint64_t* out) {
+  const uint64_t i = (uint64_t)blockIdx.x * EW_THREADS + threadIdx.x;
+  if (i >= n) return;
+  fe_store(out, i, fe_mul(fe_load(a, i), fe_load(b, i)));
+}
+
+// out[r * cols + c] = base^((row0 + r) * (col0 + c)) * mul : the twiddle block of a four-step
+// transform owned by one rank
+__global__ __launch_bounds__(EW_THREADS) void twiddle_block_kernel(uint64_t* out, uint64_t rows, uint64_t cols, uint64_t row0,
+                                                                  uint64_t col0, Fe base, Fe mul) {
+  const uint64_t i = (uint64_t)blockIdx.x * EW_THREADS + threadIdx.x;
+  if (i >= rows * cols) return;
+  const uint64_t r = i / cols, c = i % cols;
+  fe_store(out, i, fe_mul(fe_pow_u64(base, (row0 + r) * (col0 + c)), mul));
 }
 
 }  // namespace plk

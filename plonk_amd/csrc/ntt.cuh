@@ -39,6 +39,12 @@ struct NttBatch {
   const uint64_t* in[NTT_MAX_BATCH];
   uint64_t* out[NTT_MAX_BATCH];
   uint32_t kind[NTT_MAX_BATCH];   // NttInputKind, honoured by the first pass only
+  // strided mode (stride_* != 0): transform b reads in[0] + b * stride_in and writes
+  // out[0] + b * stride_out (strides in uint64_t units), kind[0] applies to all
+  uint64_t stride_in, stride_out;
+  __device__ __forceinline__ const uint64_t* src(int b) const { return stride_in ? in[0] + (uint64_t)b * stride_in : in[b]; }
+  __device__ __forceinline__ uint64_t* dst(int b) const { return stride_out ? out[0] + (uint64_t)b * stride_out : out[b]; }
+  __device__ __forceinline__ uint32_t kind_of(int b) const { return stride_in ? kind[0] : kind[b]; }
 };
 
 // Device-resident constants of one (log N, direction) transform; every table holds twiddle
@@ -148,15 +154,15 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const NttPassArgs
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const Tile tile(lds_raw);
   const int poly = blockIdx.y;
-  const uint64_t* __restrict__ in = a.batch.in[poly];
-  uint64_t* __restrict__ out = a.batch.out[poly];
+  const uint64_t* __restrict__ in = a.batch.src(poly);
+  uint64_t* __restrict__ out = a.batch.dst(poly);
   const int log_c = a.log_c, log_r = a.log_r, log_inner = a.log_inner;
   const int tiles_per_block = 1 << (log_inner - log_c);       // tiles per value of the outer digits
   const uint64_t o = blockIdx.x >> (log_inner - log_c);
   const uint64_t q0 = (uint64_t)(blockIdx.x & (tiles_per_block - 1)) << log_c;
   const uint64_t base = (o << (log_r + log_inner)) + q0;
   const int elems = 1 << (log_r + log_c);
-  const uint32_t kind = a.first ? a.batch.kind[poly] : (uint32_t)NTT_IN_FIELD;
+  const uint32_t kind = a.first ? a.batch.kind_of(poly) : (uint32_t)NTT_IN_FIELD;
 
   for (int e = threadIdx.x; e < elems; e += NTT_THREADS) {
     const int r = e >> log_c, c = e & ((1 << log_c) - 1);
@@ -199,13 +205,13 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_final_kernel(const NttFinalAr
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const Tile tile(lds_raw);
   const int poly = blockIdx.y;
-  const uint64_t* __restrict__ in = a.batch.in[poly];
-  uint64_t* __restrict__ out = a.batch.out[poly];
+  const uint64_t* __restrict__ in = a.batch.src(poly);
+  uint64_t* __restrict__ out = a.batch.dst(poly);
   const int log_c = a.log_c, log_r = a.log_r;
   const uint64_t k2 = blockIdx.x & ((1u << a.log_r2) - 1);
   const uint64_t k1_0 = (uint64_t)(blockIdx.x >> a.log_r2) << log_c;
   const int elems = 1 << (log_r + log_c);
-  const uint32_t kind = a.first ? a.batch.kind[poly] : (uint32_t)NTT_IN_FIELD;
+  const uint32_t kind = a.first ? a.batch.kind_of(poly) : (uint32_t)NTT_IN_FIELD;
 
   // tile[bitrev(r)][c] <- row o_c = (k1_0 + c) * R2 + k2, element r.  Threads run along r so that
   // each row is read as one contiguous stream.

@@ -120,6 +120,50 @@ class DeviceProver:
                                                 z_shift, _ptr(z), _ptr(g), _ptr(p)))
         return z, g, p
 
+    # -- pieces of the multi-GPU paths (plonk_amd.dist)
+    def grand_product_cols(self, wires, sigma, n: int, beta, gamma) -> torch.Tensor:
+        z = self.empty(n + 1)
+        b, g = _host_fe(beta), _host_fe(gamma)
+        self.ctx.check(self.lib.plk_dev_grand_product(self.ctx.handle, self._stream(), _table(wires), _table(sigma), n,
+                                                      b.ctypes.data_as(_lib.u64p), g.ctypes.data_as(_lib.u64p), _ptr(z)))
+        return z
+
+    def gate_constraint_chunk(self, wire_evals, sel_evals, count: int) -> torch.Tensor:
+        out = self.empty(count)
+        self.ctx.check(self.lib.plk_dev_gate_constraint_eval(self.ctx.handle, self._stream(), _table(wire_evals), _table(sel_evals),
+                                                             count, _ptr(out)))
+        return out
+
+    def perm_constraint_chunk(self, z_evals, sigma_evals, wire_evals, count: int, index0: int, N: int, beta, gamma,
+                              z_shift: int = 1) -> torch.Tensor:
+        """`count` points from `index0`; z_evals carries count + z_shift points (range + halo)."""
+        out = self.empty(count)
+        b, g = _host_fe(beta), _host_fe(gamma)
+        self.ctx.check(self.lib.plk_dev_perm_constraint_eval_range(self.ctx.handle, self._stream(), _ptr(z_evals), _table(sigma_evals),
+                                                                   _table(wire_evals), count, index0, b.ctypes.data_as(_lib.u64p),
+                                                                   g.ctypes.data_as(_lib.u64p), z_shift, _ptr(out)))
+        return out
+
+    def ntt_rows(self, mat: torch.Tensor, N: int, inverse: bool = False) -> torch.Tensor:
+        """Independent transforms of the rows of a contiguous `[rows, len, 4]` matrix -> `[rows, N, 4]`."""
+        rows, length = mat.shape[0], mat.shape[1]
+        out = torch.empty((rows, N, 4), dtype=torch.int64, device=self.device)
+        self.ctx.check(self.lib.plk_dev_ntt_strided(self.ctx.handle, self._stream(), _ptr(mat), length, _lib.INPUT_FIELD, rows,
+                                                    length, N, 1 if inverse else 0, _ptr(out), N))
+        return out
+
+    def mul(self, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+        out = torch.empty_like(a)
+        self.ctx.check(self.lib.plk_dev_mul(self.ctx.handle, self._stream(), _ptr(a), _ptr(b), a.numel() // 4, _ptr(out)))
+        return out
+
+    def twiddle_block(self, N: int, rows: int, cols: int, row0: int, col0: int = 0, inverse: bool = False,
+                      scale_by_inverse_n: bool = False) -> torch.Tensor:
+        out = torch.empty((rows, cols, 4), dtype=torch.int64, device=self.device)
+        self.ctx.check(self.lib.plk_dev_twiddle_block(self.ctx.handle, self._stream(), N, 1 if inverse else 0,
+                                                      1 if scale_by_inverse_n else 0, rows, cols, row0, col0, _ptr(out)))
+        return out
+
     # -- per-launch timing
     def profile_begin(self):
         self.lib.plk_profile_begin(self.ctx.handle)

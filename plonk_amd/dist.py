@@ -1,0 +1,140 @@
+"""Multi-GPU forms of the hot path: one process per GPU, torch.distributed (RCCL on GPUs, gloo on
+CPU for the tests) for the exchanges, libplonk_hip.so for every local computation.
+
+Three ways the path shards (the reference has no distribution of any kind):
+
+* `shard_circuits`  - batched proofs: whole circuits round-robin over ranks, no collective.
+* `four_step_ntt`   - ONE transform of size N over G ranks.  N = N1 * N2 is viewed as an
+  N1 x N2 matrix (n = n1 * N2 + n2, k = k1 + N1 * k2).  Ranks hold contiguous index ranges, i.e.
+  blocks of rows.  all-to-all -> column transforms (size N1) -> twiddle omega_N^(k1 n2) ->
+  all-to-all -> row transforms (size N2) -> all-to-all back to natural order.  Each all-to-all
+  moves (G-1)/G of a rank's N/G elements, one message per peer - on MI355X one per xGMI link.
+* `round23_poly_sharded` - ONE proof over G ranks: the 18 columns are dealt to the ranks for
+  interpolation and extension, one all-to-all turns "my columns, all points" into "all columns,
+  my points" (plus a one-point halo of Z), and every rank evaluates the constraints on its range.
+
+The local computations come from an `engine` object (plonk_amd.device.DeviceProver on GPUs); the
+tensors are `(n, 4) int64` rows of Montgomery limbs on the engine's device.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def _world(group=None):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def _all_to_all(send: torch.Tensor, group=None) -> torch.Tensor:
+    """send[h] goes to rank h; returns recv with recv[g] = what rank g sent to us."""
+    _, world = _world(group)
+    if world == 1:
+        return send
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send.contiguous(), group=group)
+    return recv
+
+
+def shard_circuits(num_circuits: int, group=None) -> List[int]:
+    """Circuit ids this rank proves in batched-proof mode (round-robin; no data-path collective)."""
+    rank, world = _world(group)
+    return list(range(rank, num_circuits, world))
+
+
+def split_domain(N: int):
+    """N = N1 * N2 with N1 >= N2, both powers of two."""
+    log_n = N.bit_length() - 1
+    if N <= 0 or (1 << log_n) != N:
+        raise ValueError("N must be a power of two")
+    n1 = 1 << ((log_n + 1) // 2)
+    return n1, N // n1
+
+
+def four_step_ntt(x_local: torch.Tensor, N: int, engine, group=None, inverse: bool = False,
+                  natural_output: bool = True) -> torch.Tensor:
+    """Transform of size N whose input is sharded contiguously by index: this rank passes
+    elements [rank * N/G, (rank + 1) * N/G).  Returns the same range of the result
+    (natural_output=True) or, saving the last exchange, the block [k1 in my rows][all k2] holding
+    X[k1 + N1 * k2] as an `(N1/G, N2, 4)` tensor."""
+    rank, G = _world(group)
+    N1, N2 = split_domain(N)
+    if N1 % G or N2 % G:
+        raise ValueError(f"{G} ranks do not divide the {N1} x {N2} view of the domain")
+    r1, c2 = N1 // G, N2 // G
+    if x_local.shape != (N // G, 4):
+        raise ValueError(f"expected a ({N // G}, 4) shard, got {tuple(x_local.shape)}")
+
+    # exchange 1: my rows, everyone's columns  ->  everyone's rows, my columns
+    send = x_local.view(r1, G, c2, 4).permute(1, 0, 2, 3).contiguous()
+    recv = _all_to_all(send, group)
+    cols = recv.view(N1, c2, 4).permute(1, 0, 2).contiguous()           # [my column][n1]
+    cols = engine.ntt_rows(cols, N1, inverse=inverse)                   # [my column][k1]
+    tw = engine.twiddle_block(N, rows=c2, cols=N1, row0=rank * c2, col0=0, inverse=inverse)
+    cols = engine.mul(cols, tw)                                         # * omega_N^(n2 * k1)
+
+    # exchange 2: my columns (n2), everyone's k1  ->  my k1 rows, every n2
+    send = cols.view(c2, G, r1, 4).permute(1, 0, 2, 3).contiguous()
+    recv = _all_to_all(send, group)
+    rows = recv.view(N2, r1, 4).permute(1, 0, 2).contiguous()           # [my k1][n2]
+    rows = engine.ntt_rows(rows, N2, inverse=inverse)                   # [my k1][k2] = X[k1 + N1 k2]
+    if not natural_output:
+        return rows
+
+    # exchange 3: back to contiguous ranges of k = k1 + N1 * k2 (k2 is the slow digit)
+    send = rows.view(r1, G, c2, 4).permute(1, 0, 2, 3).contiguous()
+    recv = _all_to_all(send, group)
+    return recv.view(N1, c2, 4).permute(1, 0, 2).contiguous().view(N // G, 4)   # [my k2][k1]
+
+
+def assign_columns(num_columns: int, group=None) -> List[int]:
+    """Columns (0..num_columns-1) this rank interpolates and extends in `round23_poly_sharded`."""
+    rank, world = _world(group)
+    return list(range(rank, num_columns, world))
+
+
+def round23_poly_sharded(engine, wires: Sequence[torch.Tensor], selectors: Sequence[Optional[torch.Tensor]],
+                         sigma: Sequence[torch.Tensor], beta, gamma, n: int, N: int, z_shift: int = 1, group=None):
+    """Rounds 2+3 of ONE circuit over all ranks.  Every rank holds the input columns (n rows each).
+    Returns (z [n+1] replicated, gate-constraint chunk, permutation-constraint chunk) where the
+    chunks cover evaluation points [rank * N/G, (rank + 1) * N/G).
+
+    Column numbering: wires 0-3, selectors 4-12 (ASTKind order, None = absent), sigma 13-16, Z 17."""
+    rank, G = _world(group)
+    if N % G:
+        raise ValueError("ranks must divide the evaluation domain")
+    chunk = N // G
+    z = engine.grand_product_cols(wires, sigma, n, beta, gamma)        # replicated: cheap next to the transforms
+    cols: List[Optional[torch.Tensor]] = list(wires) + list(selectors) + list(sigma) + [z[:n]]
+    kinds = [0] * 13 + [1] * 4 + [0]
+    present = [i for i, c in enumerate(cols) if c is not None]
+    mine = [present[i] for i in assign_columns(len(present), group)]
+    per_rank = (len(present) + G - 1) // G
+
+    # my columns: interpolate, extend to N points
+    evals = torch.zeros((per_rank, N + z_shift, 4), dtype=torch.int64, device=z.device)
+    if mine:
+        coefs = engine.ntt_batch([cols[i].contiguous() for i in mine], n, inverse=True, kinds=[kinds[i] for i in mine])
+        ext = engine.ntt_batch(coefs, N)
+        for slot, e in enumerate(ext):
+            evals[slot, :N] = e
+            evals[slot, N:] = e[:z_shift]                                # wrap-around halo for z[(i + shift) mod N]
+    # exchange: slot-major, all points  ->  every rank's slots, my points (+ halo)
+    send = torch.stack([evals[:, h * chunk:(h + 1) * chunk + z_shift] for h in range(G)]).contiguous()   # [G][slot][chunk+halo]
+    recv = _all_to_all(send, group)                                      # [source rank][slot][chunk+halo]
+    local = {}
+    for src in range(G):
+        src_cols = [present[i] for i in range(src, len(present), G)]
+        for slot, col in enumerate(src_cols):
+            local[col] = recv[src, slot]
+    w_ev = [local[i][:chunk].contiguous() for i in range(4)]
+    s_ev = [local[4 + k][:chunk].contiguous() if (4 + k) in local else None for k in range(9)]
+    g_ev = [local[13 + k][:chunk].contiguous() for k in range(4)]
+    z_ev = local[17].contiguous()                                        # chunk + halo points
+    gate = engine.gate_constraint_chunk(w_ev, s_ev, chunk)
+    perm = engine.perm_constraint_chunk(z_ev, g_ev, w_ev, chunk, rank * chunk, N, beta, gamma, z_shift)
+    return z, gate, perm

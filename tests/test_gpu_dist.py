@@ -1,0 +1,65 @@
+"""GPU tests of the multi-GPU building blocks on one GPU (world size 1: the exchanges are the
+identity, every local computation is the HIP library's)."""
+import numpy as np
+import pytest
+import torch
+
+import c_oracle as co
+import plonk_oracle as po
+from plonk_amd import dist as pdist
+from plonk_amd import synth
+from plonk_amd.device import to_device, to_host
+
+pytestmark = pytest.mark.gpu
+
+
+def test_strided_rows_mul_and_twiddles(prover):
+    rows, length, N = 37, 64, 256
+    mat = synth.random_elements(91, rows * length).reshape(rows, length, 4)
+    got = to_host(prover.ntt_rows(to_device(mat, prover.device), N))
+    for r in (0, 1, 17, 36):
+        assert np.array_equal(got[r], co.ntt(mat[r], N))
+    inv = to_host(prover.ntt_rows(to_device(mat, prover.device), length, inverse=True))
+    assert np.array_equal(inv[5], co.intt(mat[5], length))
+    a, b = synth.random_elements(1, 500), synth.random_elements(2, 500)
+    prod = to_host(prover.mul(to_device(a, prover.device), to_device(b, prover.device)))
+    assert all(np.array_equal(prod[i], co.fe_mul(a[i], b[i])) for i in (0, 3, 499))
+    tw = synth.mont_to_ints(to_host(prover.twiddle_block(1 << 20, rows=3, cols=5, row0=1000, col0=7)).reshape(-1, 4))
+    w = po.root_of_unity(1 << 20)
+    assert tw == [pow(w, (1000 + r) * (7 + c), po.P) for r in range(3) for c in range(5)]
+    twi = synth.mont_to_ints(to_host(prover.twiddle_block(1 << 10, 2, 2, 3, 0, inverse=True, scale_by_inverse_n=True)).reshape(-1, 4))
+    wi, ninv = pow(po.root_of_unity(1 << 10), -1, po.P), pow(1 << 10, -1, po.P)
+    assert twi == [pow(wi, (3 + r) * c, po.P) * ninv % po.P for r in range(2) for c in range(2)]
+
+
+@pytest.mark.parametrize("log_n", [8, 13, 16])
+def test_four_step_matches_direct_transform(prover, log_n):
+    N = 1 << log_n
+    x = synth.random_elements(300 + log_n, N)
+    xd = to_device(x, prover.device)
+    got = pdist.four_step_ntt(xd, N, prover)
+    assert np.array_equal(to_host(got), co.ntt(x, N))
+    back = pdist.four_step_ntt(got, N, prover, inverse=True)
+    assert torch.equal(back, xd)
+
+
+def test_four_step_2_24_roundtrip_and_agreement(prover):
+    """BASELINE config 4's size on one GPU: the four-step result equals the library's direct
+    three-pass transform (itself checked against the oracle) and inverts back to the input."""
+    N = 1 << 24
+    x = to_device(synth.random_elements(77, N), prover.device)
+    direct = prover.ntt_batch([x], N)[0]
+    four = pdist.four_step_ntt(x, N, prover)
+    assert torch.equal(four, direct)
+    assert torch.equal(pdist.four_step_ntt(four, N, prover, inverse=True), x)
+
+
+def test_poly_sharded_round23_single_rank(prover):
+    n, N = 1 << 12, 1 << 14
+    c = synth.make_circuit(n, circuit_id=5)
+    dc = prover.upload(c)
+    sels = [dc.selectors.get(k) for k in po.AST_KINDS]
+    z, g, e = pdist.round23_poly_sharded(prover, dc.wires, sels, dc.sigma, c.beta, c.gamma, n, N)
+    prover.status()
+    zr, gr, er = co.round23(c.table.wires(), c.table.selectors, c.perm.columns(), N, c.beta, c.gamma)
+    assert np.array_equal(to_host(z), zr) and np.array_equal(to_host(g), gr) and np.array_equal(to_host(e), er)
