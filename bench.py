@@ -37,6 +37,11 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-n", type=int, default=20, help="log2 of the number of rows")
     ap.add_argument("--blowup", type=int, default=4, help="evaluation domain = blowup * n")
+    ap.add_argument("--workload", default="round23", choices=["round23", "ntt", "round23-sharded", "batch"],
+                    help="round23: the headline metric (default). ntt: ONE four-step transform of 2^log-n points sharded over "
+                         "the GPUs (config 4 with --log-n 24). round23-sharded: ONE proof over all GPUs. "
+                         "batch: --circuits independent circuits dealt round-robin (config 5 with --log-n 18 --circuits 64)")
+    ap.add_argument("--circuits", type=int, default=64)
     ap.add_argument("--cpu-sample-log-n", type=int, default=16, help="rows of the CPU-baseline sample (log2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -77,6 +82,86 @@ def pmc_traffic(label: str):
     return None, None
 
 
+def timed(fn, steps, warmup, dist, device):
+    """warm up, then time `steps` calls between barriers; max over ranks; seconds."""
+    import torch
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        fn()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def other_workloads(args, prover, dist, rank, world):
+    """The multi-GPU shapes that are not the headline metric (run explicitly with --workload)."""
+    from plonk_amd import dist as pdist
+    from plonk_amd import synth
+    from plonk_amd.api import AST_KINDS
+    from plonk_amd.device import to_device
+    n = 1 << args.log_n
+    base = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dtype": "u32", "data": "synthetic", "vs_baseline": None}
+    if args.workload == "ntt":
+        N = n
+        x = to_device(synth.random_elements(99 + rank, N // world), prover.device)
+        dt = timed(lambda: pdist.four_step_ntt(x, N, prover), args.steps, args.warmup, dist, prover.device)
+        ms = dt * 1e3 / args.steps
+        gelem = N / (ms * 1e-3) / 1e9
+        line = dict(base, metric=f"four-step NTT of 2^{args.log_n} points, natural order in and out", value=round(gelem, 3),
+                    unit="Gelem/s", ms_per_step=round(ms, 4), higher_is_better=True, scaling="strong",
+                    config={"workload": f"one transform of N=2^{args.log_n} sharded contiguously over {world} GPU(s), three "
+                                        f"all-to-all exchanges of {(world - 1) * N // (world * world) * 32 / 2**20:.1f} MiB per GPU each"},
+                    frac_of_hbm_roofline=round(gelem / NTT_ROOFLINE_GELEM, 4))
+    elif args.workload == "round23-sharded":
+        N = args.blowup * n
+        c = synth.make_circuit(n, circuit_id=0)
+        dc = prover.upload(c)
+        sels = [dc.selectors.get(k) for k in AST_KINDS]
+        dt = timed(lambda: pdist.round23_poly_sharded(prover, dc.wires, sels, dc.sigma, c.beta, c.gamma, n, N), args.steps,
+                   args.warmup, dist, prover.device)
+        prover.status()
+        ms = dt * 1e3 / args.steps
+        line = dict(base, metric=f"prover round 2+3 time at n=2^{args.log_n}, one proof over all GPUs", value=round(ms, 4), unit="ms",
+                    ms_per_step=round(ms, 4), higher_is_better=False, scaling="strong",
+                    config={"workload": f"one circuit, columns dealt to {world} GPU(s) for interpolation/extension, one all-to-all, "
+                                        f"constraints on N/{world} points per GPU"})
+    else:  # batch
+        N = args.blowup * n
+        ids = pdist.shard_circuits(args.circuits)
+        circuits = [prover.upload(synth.make_circuit(n, circuit_id=i)) for i in ids]
+        out = (prover.empty(n + 1), prover.empty(N), prover.empty(N))
+
+        def step():
+            for dc in circuits:
+                prover.round23(dc, N, out=out)
+        dt = timed(step, args.steps, args.warmup, dist, prover.device)
+        prover.status()
+        ms = dt * 1e3 / args.steps
+        line = dict(base, metric=f"proof throughput, {args.circuits} circuits of n=2^{args.log_n} (rounds 2+3)",
+                    value=round(args.circuits / (ms * 1e-3), 2), unit="proofs/s", ms_per_step=round(ms, 4), higher_is_better=True,
+                    scaling="strong", config={"workload": f"{args.circuits} independent circuits dealt round-robin over {world} GPU(s), "
+                                                          f"no collective"})
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse_args()
     import torch
@@ -94,6 +179,8 @@ def main():
     n, N = 1 << args.log_n, args.blowup << args.log_n
 
     prover = DeviceProver(local_rank)
+    if args.workload != "round23":
+        return other_workloads(args, prover, dist, rank, world)
     circuit = synth.make_circuit(n, circuit_id=rank)
     dc = prover.upload(circuit)
     out = (prover.empty(n + 1), prover.empty(N), prover.empty(N))

@@ -74,7 +74,12 @@ def four_step_ntt(x_local: torch.Tensor, N: int, engine, group=None, inverse: bo
     recv = _all_to_all(send, group)
     cols = recv.view(N1, c2, 4).permute(1, 0, 2).contiguous()           # [my column][n1]
     cols = engine.ntt_rows(cols, N1, inverse=inverse)                   # [my column][k1]
-    tw = engine.twiddle_block(N, rows=c2, cols=N1, row0=rank * c2, col0=0, inverse=inverse)
+    # this rank's twiddle block is a constant of (N, rank, G, direction): built once, kept on the engine
+    cache = engine.__dict__.setdefault("_four_step_twiddles", {})
+    key = (N, rank, G, inverse)
+    if key not in cache:
+        cache[key] = engine.twiddle_block(N, rows=c2, cols=N1, row0=rank * c2, col0=0, inverse=inverse)
+    tw = cache[key]
     cols = engine.mul(cols, tw)                                         # * omega_N^(n2 * k1)
 
     # exchange 2: my columns (n2), everyone's k1  ->  my k1 rows, every n2
