@@ -48,6 +48,11 @@ constexpr uint32_t kp_word32(int k, int j) {
 constexpr uint32_t q2_limb(int i) {
   return i == 0 ? kp_limb29(2, 0) + (1u << 29) : (i < 8 ? kp_limb29(2, i) + (1u << 29) - 1 : kp_limb29(2, 8) - 1);
 }
+// 4p with every low limb raised by 2^30 (covers a subtrahend whose limbs are sums of two
+// normalised limbs)
+constexpr uint32_t q4_limb(int i) {
+  return i == 0 ? kp_limb29(4, 0) + (1u << 30) : (i < 8 ? kp_limb29(4, i) + (1u << 30) - 2 : kp_limb29(4, 8) - 2);
+}
 }  // namespace f9c
 
 // ---- conversions -------------------------------------------------------------------------
@@ -158,6 +163,14 @@ __device__ __forceinline__ F9 f9_sub_q2(const F9& a, const F9& t) {
   F9 r;
 #pragma unroll
   for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] + (f9c::q2_limb(i) - t.l[i]);
+  return r;
+}
+
+// a - t + 4p, limb-wise; t = sum of two normalised values (limbs <= 2^30 - 2, value < 4p - 2^233)
+__device__ __forceinline__ F9 f9_sub_q4(const F9& a, const F9& t) {
+  F9 r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] + (f9c::q4_limb(i) - t.l[i]);
   return r;
 }
 

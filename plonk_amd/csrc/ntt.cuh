@@ -30,7 +30,8 @@ constexpr int NTT_TILE = 1 << NTT_TILE_LOG;
 constexpr int NTT_THREADS = 512;
 constexpr int NTT_MAX_BATCH = 24;           // columns per launch
 constexpr int NTT_MASTER_LOG = 11;          // per-tile twiddles: omega_{2^11}^e, e < 2^10
-constexpr size_t NTT_LDS_BYTES = (size_t)NTT_TILE * 36;   // 9 words per element
+constexpr int NTT_LDS_TW_LOG = 7;           // per-tile twiddles kept in LDS when the radix is <= 2^8
+constexpr size_t NTT_LDS_BYTES = ((size_t)NTT_TILE + (1 << NTT_LDS_TW_LOG)) * 36;   // 9 words per element
 constexpr int TW_WORDS = 12;                // one twiddle record (9 limbs + padding)
 
 enum NttInputKind : uint32_t { NTT_IN_FIELD = 0, NTT_IN_U64 = 1 };
@@ -67,8 +68,8 @@ __device__ __forceinline__ uint32_t bitrev(uint32_t x, int bits) { return bits ?
 // LDS tile: element e -> limbs 0-3 at A[e], limbs 4-7 at B[e] (16 bytes each), limb 8 at C[e]
 struct Tile {
   uint4* A; uint4* B; uint32_t* C;
-  __device__ __forceinline__ explicit Tile(void* base)
-      : A(reinterpret_cast<uint4*>(base)), B(A + NTT_TILE), C(reinterpret_cast<uint32_t*>(B + NTT_TILE)) {}
+  __device__ __forceinline__ explicit Tile(void* base, int elems = NTT_TILE)
+      : A(reinterpret_cast<uint4*>(base)), B(A + elems), C(reinterpret_cast<uint32_t*>(B + elems)) {}
   __device__ __forceinline__ F9 get(int e) const {
     const uint4 a = A[e], b = B[e];
     F9 r;
@@ -102,14 +103,48 @@ __device__ __forceinline__ F9 load_input(const uint64_t* in, uint64_t idx, bool 
   return v;
 }
 
+// The first two stages of the tile transform as one radix-4 step in registers: rows 4i..4i+3 of
+// the bit-reversed tile, one multiplication (by omega_4) per four elements, no LDS round trip in
+// between.  `quarter`: only row 4i is non-zero (an n -> 4n extension's first pass), so the four
+// outputs are copies of it.  Outputs normalised, value < 7.2 p.
+__device__ __forceinline__ void tile_first_radix4(const Tile& t, int log_r, int log_c, const uint32_t* master, bool quarter) {
+  const int groups = 1 << (log_r + log_c - 2);
+  const F9 w4 = f9_load_tw(master, (size_t)1 << (NTT_MASTER_LOG - 2));   // omega_4 (or its inverse)
+  for (int g = threadIdx.x; g < groups; g += NTT_THREADS) {
+    const int c = g & ((1 << log_c) - 1), i = g >> log_c;
+    const int e0 = ((4 * i) << log_c) + c, step = 1 << log_c;
+    const F9 a0 = t.get(e0);
+    if (quarter) {
+      t.put(e0 + step, a0); t.put(e0 + 2 * step, a0); t.put(e0 + 3 * step, a0);
+      continue;
+    }
+    const F9 a1 = t.get(e0 + step), a2 = t.get(e0 + 2 * step), a3 = t.get(e0 + 3 * step);
+    const F9 u0 = f9_add(a0, a1), u1 = f9_sub_q2(a0, a1), u2 = f9_add(a2, a3);
+    const F9 u3 = mont29(f9_sub_q2(a2, a3), w4);
+    F9 y0 = f9_add(u0, u2), y2 = f9_sub_q4(u0, u2), y1 = f9_add(u1, u3), y3 = f9_sub_q2(u1, u3);
+    f9_normalize(y0); f9_normalize(y1); f9_normalize(y2); f9_normalize(y3);
+    t.put(e0, y0); t.put(e0 + step, y1); t.put(e0 + 2 * step, y2); t.put(e0 + 3 * step, y3);
+  }
+  __syncthreads();
+}
+
 // In-LDS decimation-in-time transform of size 2^log_r along the row axis of a
 // [2^log_r][2^log_c] tile whose rows were stored in bit-reversed order; leaves natural order.
-// Outputs are lazy: limbs < 1.5 * 2^30, value < (2 + 2 log_r) p.
-__device__ __forceinline__ void tile_dit(const Tile& t, int log_r, int log_c, const uint32_t* master) {
+// Outputs are lazy: limbs < 1.3 * 2^31, value < (4 + 2 log_r) p.
+__device__ __forceinline__ void tile_dit(const Tile& t, int log_r, int log_c, const uint32_t* master, bool quarter) {
   const int total = 1 << (log_r + log_c - 1);  // butterflies per stage
-  for (int lh = 0; lh < log_r; ++lh) {
+  // the 2^(log_r - 1) twiddles of this radix, omega_R^j, copied next to the tile when they fit
+  const Tile ltw(reinterpret_cast<unsigned char*>(t.A) + (size_t)NTT_TILE * 36, 1 << NTT_LDS_TW_LOG);
+  const bool tw_lds = log_r - 1 <= NTT_LDS_TW_LOG;
+  if (tw_lds) {
+    for (int j = threadIdx.x; j < (1 << (log_r - 1)); j += NTT_THREADS)
+      ltw.put(j, f9_load_tw(master, (size_t)j << (NTT_MASTER_LOG - log_r)));
+  }
+  int first = 0;
+  if (log_r >= 2) { tile_first_radix4(t, log_r, log_c, master, quarter); first = 2; }
+  for (int lh = first; lh < log_r; ++lh) {
     const int h = 1 << lh;
-    const bool renorm = (lh & 1) != 0;         // after every second stage
+    const bool renorm = ((lh - first) & 1) != 0;   // after every second stage
     for (int b = threadIdx.x; b < total; b += NTT_THREADS) {
       const int c = b & ((1 << log_c) - 1);
       const int q = b >> log_c;
@@ -118,7 +153,7 @@ __device__ __forceinline__ void tile_dit(const Tile& t, int log_r, int log_c, co
       const int e0 = (i0 << log_c) + c, e1 = ((i0 + h) << log_c) + c;
       const F9 x = t.get(e0);
       F9 y = t.get(e1);
-      if (lh > 0) y = mont29(y, f9_load_tw(master, (size_t)j << (NTT_MASTER_LOG - 1 - lh)));
+      if (lh > 0) y = mont29(y, tw_lds ? ltw.get(j << (log_r - 1 - lh)) : f9_load_tw(master, (size_t)j << (NTT_MASTER_LOG - 1 - lh)));
       F9 u = f9_add(x, y), v = f9_sub_q2(x, y);
       if (renorm) { f9_normalize(u); f9_normalize(v); }
       t.put(e0, u);
@@ -171,7 +206,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const NttPassArgs
     tile.put((int)(bitrev((uint32_t)r, log_r) << log_c) + c, v);
   }
   __syncthreads();
-  tile_dit(tile, log_r, log_c, a.tab.master);
+  tile_dit(tile, log_r, log_c, a.tab.master, a.first && log_r >= 2 && (a.n_in << 2) <= (1ull << a.log_n));
 
   // inter-pass twiddle omega_{N'}^(k * q), N' = 2^(log_r + log_inner), as a power of omega_N
   const int shift = a.log_n - (log_r + log_inner);
@@ -223,7 +258,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_final_kernel(const NttFinalAr
     tile.put((int)(bitrev((uint32_t)r, log_r) << log_c) + c, v);
   }
   __syncthreads();
-  tile_dit(tile, log_r, log_c, a.tab.master);
+  tile_dit(tile, log_r, log_c, a.tab.master, a.first && log_r >= 2 && (a.n_in << 2) <= (1ull << a.log_n));
 
   const bool scaled = a.tab.scale != nullptr;
   F9 sc;
