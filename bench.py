@@ -229,7 +229,7 @@ def main():
                         "note": "a transform of N points over B columns is 64*N*B algorithmic bytes (160*n*B for an n -> 4n "
                                 "extension); each of its P launches is credited 1/P of that"}
         # whole-transform throughput of the extension (all launches of the N-point forward transform)
-        lde = [r for r in prof if f"/ntt{args.log_n + args.blowup.bit_length() - 1}" in r["label"]]
+        lde = [r for r in prof if f"/ntt{args.log_n + args.blowup.bit_length() - 1}" in r["label"] or "/lde" in r["label"]]
         ntt = None
         if lde:
             lde_ms = sum(r["total_ms"] for r in lde) / args.steps

@@ -33,7 +33,7 @@ struct NttPlan {
   int npass = 1;
   int log_r[3] = {0, 0, 0};
   NttTables tab{};
-  DevBuf master, hi, hi_scaled, lo, scale, from_u64, full[2];
+  DevBuf master, hi, hi_scaled, lo, scale, from_u64, full[2], prescale4;
 };
 
 }  // namespace
@@ -224,16 +224,33 @@ int get_plan(plk_ctx* ctx, int log_n, bool inverse, hipStream_t s, NttPlan** out
 // Enqueue `batch` transforms.  Columns are given either as pointer tables (stride_in/out == 0,
 // batch <= NTT_MAX_BATCH) or as one base pointer plus a stride in elements.
 int launch_ntt(plk_ctx* ctx, hipStream_t s, const uint64_t* const* in, const uint32_t* kinds, size_t batch,
-               size_t n_in, size_t N, bool inverse, uint64_t* const* out, size_t stride_in = 0, size_t stride_out = 0) {
+               size_t n_in, size_t N, bool inverse, uint64_t* const* out, size_t stride_in = 0, size_t stride_out = 0,
+               int cosets = 0) {
   int log_n, rc;
   if ((rc = check_domain(ctx, N, &log_n))) return rc;
   if (n_in > N) return fail(ctx, PLK_ERR_LENGTH, "more input elements than domain points");
   if (batch == 0) return PLK_OK;
   const bool ptr_tables = stride_in == 0 || stride_out == 0;
   if (ptr_tables && batch > NTT_MAX_BATCH) return fail(ctx, PLK_ERR_ARG, "batch exceeds PLK_MAX_BATCH");
-  if (batch > 65535) return fail(ctx, PLK_ERR_ARG, "batch exceeds 65535");
+  const size_t slots = cosets ? batch * cosets : batch;
+  if (slots > 65535) return fail(ctx, PLK_ERR_ARG, "batch exceeds 65535");
   NttPlan* plan;
   if ((rc = get_plan(ctx, log_n, inverse, s, &plan))) return rc;
+  const uint32_t* prescale = nullptr;
+  if (cosets) {
+    // evaluation on the cosets omega_4N^r <omega_N>, r = 1..3, of the 4N-point domain
+    if (cosets != 3 || inverse || n_in != N || log_n + 2 > Field::TWO_ADICITY) return fail(ctx, PLK_ERR_ARG, "unsupported coset request");
+    if (!plan->prescale4.p) {
+      const uint64_t count = 3ull << log_n;
+      HIP_TRY(ctx, hipMalloc(&plan->prescale4.p, count * TW_WORDS * 4));
+      plan->prescale4.cap = count * TW_WORDS * 4;
+      hipLaunchKernelGGL(ntt_prescale_table_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s,
+                         (uint32_t*)plan->prescale4.p, log_n, 3, root_of_unity(log_n + 2));
+      HIP_TRY(ctx, hipGetLastError());
+      HIP_TRY(ctx, hipStreamSynchronize(s));
+    }
+    prescale = (const uint32_t*)plan->prescale4.p;
+  }
 
   NttBatch user{};   // the caller's buffers
   const size_t n_ptr_in = stride_in ? 1 : batch, n_ptr_out = stride_out ? 1 : batch;
@@ -251,15 +268,17 @@ int launch_ntt(plk_ctx* ctx, hipStream_t s, const uint64_t* const* in, const uin
   uint64_t* tmp = nullptr;
   if (plan->npass > 1) {
     void* p;
-    if ((rc = ws_get(ctx, "ntt_tmp", batch * N * ELEM, &p))) return rc;
+    if ((rc = ws_get(ctx, "ntt_tmp", slots * N * ELEM, &p))) return rc;
     tmp = (uint64_t*)p;
   }
   const size_t lds_bytes = NTT_LDS_BYTES;
   const int P = plan->npass;
   // algorithmic bytes of the whole transform group (read the inputs once, write the outputs once),
   // attributed in equal shares to its P launches
-  const double alg_share = (32.0 * (double)n_in + 32.0 * (double)N) * (double)batch / P;
-  const std::string tag = std::string(inverse ? "/intt" : "/ntt") + std::to_string(log_n) + (n_in < N ? "lde" : "");
+  // (an n -> 4n extension done as three coset transforms is credited the extension's 160 n bytes)
+  const double alg_share = (cosets ? 160.0 * (double)N : 32.0 * (double)n_in + 32.0 * (double)N) * (double)batch / P;
+  const std::string tag = cosets ? "/lde" + std::to_string(log_n) + "to" + std::to_string(log_n + 2)
+                                 : std::string(inverse ? "/intt" : "/ntt") + std::to_string(log_n) + (n_in < N ? "lde" : "");
   auto from_user = [&](NttBatch& b) { for (int i = 0; i < NTT_MAX_BATCH; ++i) { b.in[i] = user.in[i]; b.kind[i] = user.kind[i]; } b.stride_in = user.stride_in; };
   auto to_user = [&](NttBatch& b) { for (int i = 0; i < NTT_MAX_BATCH; ++i) b.out[i] = user.out[i]; b.stride_out = user.stride_out; };
   auto from_tmp = [&](NttBatch& b) { b.in[0] = tmp; b.stride_in = (uint64_t)N * 4; b.kind[0] = NTT_IN_FIELD; };
@@ -279,11 +298,13 @@ int launch_ntt(plk_ctx* ctx, hipStream_t s, const uint64_t* const* in, const uin
     a.first = p == 0;
     a.use_scaled = p == 0;
     a.pass = p;
+    a.cosets = cosets;
+    a.prescale = prescale;
     if (p == 0) from_user(a.batch); else from_tmp(a.batch);
     to_tmp(a.batch);
     const unsigned tiles = 1u << (log_n - lr - a.log_c);
     ProfScope ps(ctx, s, "ntt_pass_kernel" + tag + "/p" + std::to_string(p), alg_share);
-    hipLaunchKernelGGL(ntt_pass_kernel, dim3(tiles, (unsigned)batch), dim3(NTT_THREADS), lds_bytes, s, a);
+    hipLaunchKernelGGL(ntt_pass_kernel, dim3(tiles, (unsigned)slots), dim3(NTT_THREADS), lds_bytes, s, a);
     HIP_TRY(ctx, hipGetLastError());
   }
   {
@@ -296,11 +317,14 @@ int launch_ntt(plk_ctx* ctx, hipStream_t s, const uint64_t* const* in, const uin
     a.log_r2 = P >= 3 ? plan->log_r[1] : 0;
     a.log_c = std::min(NTT_TILE_LOG - a.log_r, a.log_r1);
     a.first = P == 1;
+    a.cosets = cosets;
+    a.prescale = prescale;
+    a.coset_stride = (uint64_t)N * 4;
     if (P == 1) from_user(a.batch); else from_tmp(a.batch);
     to_user(a.batch);
     const unsigned tiles = 1u << (log_n - a.log_r - a.log_c);
     ProfScope ps(ctx, s, "ntt_final_kernel" + tag, alg_share);
-    hipLaunchKernelGGL(ntt_final_kernel, dim3(tiles, (unsigned)batch), dim3(NTT_THREADS), lds_bytes, s, a);
+    hipLaunchKernelGGL(ntt_final_kernel, dim3(tiles, (unsigned)slots), dim3(NTT_THREADS), lds_bytes, s, a);
     HIP_TRY(ctx, hipGetLastError());
   }
   return PLK_OK;
@@ -432,6 +456,36 @@ int launch_round23(plk_ctx* ctx, hipStream_t s, const uint64_t* const wires[4], 
   for (size_t b = 0; b < m; ++b) out[b] = col_coef(col_of[b]);
   if ((rc = launch_ntt(ctx, s, in, kinds, m, n, n, true, out))) return rc;
 
+  if (N == 4 * n && log_n >= 2 && log_n + 2 <= Field::TWO_ADICITY) {
+    // The 4n-point domain is four cosets of the trace domain.  On coset 0 every column IS its
+    // table (interpolation followed by evaluation at the same points is the identity), so only
+    // cosets 1..3 are computed: three prescaled n-point transforms per column, kept coset-major.
+    auto col_cos = [&](int c) { return eval + (size_t)c * 3 * n * 4; };   // planes 1..3 of column c
+    for (size_t b = 0; b < m; ++b) { in[b] = col_coef(col_of[b]); out[b] = col_cos(col_of[b]); }
+    if ((rc = launch_ntt(ctx, s, in, nullptr, m, n, n, false, out, 0, 0, 3))) return rc;
+    if (gate_out) {
+      GateColsCoset g{};
+      int ncols = 5;
+      for (int k = 0; k < 4; ++k) { g.w0[k] = wires[k]; g.w[k] = col_cos(k); }
+      for (int k = 0; k < 9; ++k) { const bool on = sel && sel[k]; g.s0[k] = on ? sel[k] : nullptr; g.s[k] = on ? col_cos(4 + k) : nullptr; ncols += on; }
+      ProfScope ps(ctx, s, "gate_constraint_coset_kernel", 32.0 * ncols * (double)N);
+      hipLaunchKernelGGL(gate_constraint_coset_kernel, dim3((unsigned)((N + EW_THREADS - 1) / EW_THREADS)), dim3(EW_THREADS), 0, s, g,
+                         (uint64_t)n, gate_out);
+      HIP_TRY(ctx, hipGetLastError());
+    }
+    if (perm_out) {
+      const Fe fb = fe_from_limbs64(beta), fg = fe_from_limbs64(gamma);
+      PermColsCoset pc{};
+      pc.z0 = z; pc.z = col_cos(17);
+      for (int k = 0; k < 4; ++k) { pc.sig0[k] = sigma[k]; pc.sig[k] = col_cos(13 + k); pc.w0[k] = wires[k]; pc.w[k] = col_cos(k); }
+      ProfScope ps(ctx, s, "perm_constraint_coset_kernel", 320.0 * (double)N);
+      hipLaunchKernelGGL(perm_constraint_coset_kernel, dim3((unsigned)((N + EW_THREADS - 1) / EW_THREADS)), dim3(EW_THREADS), 0, s, pc,
+                         (uint64_t)n, fb, fg, fe_mul(fb, fe_r2()), (uint64_t)(z_shift % N), perm_out);
+      HIP_TRY(ctx, hipGetLastError());
+    }
+    return PLK_OK;
+  }
+
   // evaluation of every coefficient vector on the N-point domain (wires once, shared by both checks)
   for (size_t b = 0; b < m; ++b) { in[b] = col_coef(col_of[b]); out[b] = col_eval(col_of[b]); }
   if ((rc = launch_ntt(ctx, s, in, nullptr, m, n, N, false, out))) return rc;
@@ -539,7 +593,7 @@ void plk_ctx_destroy(plk_ctx* ctx) {
   (void)hipDeviceSynchronize();
   for (auto& kv : ctx->plans) {
     NttPlan& p = kv.second;
-    for (DevBuf* b : {&p.master, &p.hi, &p.hi_scaled, &p.lo, &p.scale, &p.from_u64, &p.full[0], &p.full[1]}) if (b->p) (void)hipFree(b->p);
+    for (DevBuf* b : {&p.master, &p.hi, &p.hi_scaled, &p.lo, &p.scale, &p.from_u64, &p.full[0], &p.full[1], &p.prescale4}) if (b->p) (void)hipFree(b->p);
   }
   for (auto& kv : ctx->ws) if (kv.second.p) (void)hipFree(kv.second.p);
   for (auto& r : ctx->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }

@@ -132,12 +132,13 @@ __device__ __forceinline__ void tile_first_radix4(const Tile& t, int log_r, int 
 // [2^log_r][2^log_c] tile whose rows were stored in bit-reversed order; leaves natural order.
 // Outputs are lazy: limbs < 1.3 * 2^31, value < (4 + 2 log_r) p.
 __device__ __forceinline__ void tile_dit(const Tile& t, int log_r, int log_c, const uint32_t* master, bool quarter) {
-  const int total = 1 << (log_r + log_c - 1);  // butterflies per stage
+  const int total = log_r >= 1 ? 1 << (log_r + log_c - 1) : 0;  // butterflies per stage
   // the 2^(log_r - 1) twiddles of this radix, omega_R^j, copied next to the tile when they fit
   const Tile ltw(reinterpret_cast<unsigned char*>(t.A) + (size_t)NTT_TILE * 36, 1 << NTT_LDS_TW_LOG);
-  const bool tw_lds = log_r - 1 <= NTT_LDS_TW_LOG;
+  const bool tw_lds = log_r >= 1 && log_r - 1 <= NTT_LDS_TW_LOG;
   if (tw_lds) {
-    for (int j = threadIdx.x; j < (1 << (log_r - 1)); j += NTT_THREADS)
+    const int count = 1 << (log_r - 1);
+    for (int j = threadIdx.x; j < count; j += NTT_THREADS)
       ltw.put(j, f9_load_tw(master, (size_t)j << (NTT_MASTER_LOG - log_r)));
   }
   int first = 0;
@@ -182,15 +183,21 @@ struct NttPassArgs {
   int first;         // 1 = reads the caller's input (kinds, zero padding)
   int use_scaled;    // 1 = take tw_hi_scaled for the inter-pass twiddle
   int pass;          // index of this pass (selects tw_full)
+  // coset mode (cosets > 0): slot blockIdx.y = column * cosets + r evaluates column `column` on
+  // the coset omega_M^(r+1) * <omega_N> (M = blowup * N) by scaling input j with
+  // prescale[r * N + j] = omega_M^((r+1) j) before the transform
+  int cosets;
+  const uint32_t* prescale;
 };
 
 // Non-final pass: digit transform + inter-pass twiddle; out may alias in when !first.
 __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const NttPassArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const Tile tile(lds_raw);
-  const int poly = blockIdx.y;
+  const int slot = blockIdx.y;
+  const int poly = (a.first && a.cosets) ? slot / a.cosets : slot;
   const uint64_t* __restrict__ in = a.batch.src(poly);
-  uint64_t* __restrict__ out = a.batch.dst(poly);
+  uint64_t* __restrict__ out = a.batch.dst(slot);
   const int log_c = a.log_c, log_r = a.log_r, log_inner = a.log_inner;
   const int tiles_per_block = 1 << (log_inner - log_c);       // tiles per value of the outer digits
   const uint64_t o = blockIdx.x >> (log_inner - log_c);
@@ -202,7 +209,8 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const NttPassArgs
   for (int e = threadIdx.x; e < elems; e += NTT_THREADS) {
     const int r = e >> log_c, c = e & ((1 << log_c) - 1);
     const uint64_t idx = base + ((uint64_t)r << log_inner) + c;
-    const F9 v = load_input(in, idx, !(a.first && idx >= a.n_in), kind, a.tab.from_u64);
+    F9 v = load_input(in, idx, !(a.first && idx >= a.n_in), kind, a.tab.from_u64);
+    if (a.first && a.cosets) v = mont29(v, f9_load_tw(a.prescale, ((uint64_t)(slot % a.cosets) << a.log_n) + idx));
     tile.put((int)(bitrev((uint32_t)r, log_r) << log_c) + c, v);
   }
   __syncthreads();
@@ -233,15 +241,21 @@ struct NttFinalArgs {
   int log_r2;     // radix of pass 2 (0 unless there are three passes)
   int log_c;      // rows (consecutive k1) per tile
   int first;
+  // coset mode, as in NttPassArgs; slot r of column b is written at out[b] + r * coset_stride
+  int cosets;
+  const uint32_t* prescale;
+  uint64_t coset_stride;   // in uint64_t units
 };
 
 // Last pass: contiguous rows in, natural-order scatter out (never in place), canonical values.
 __global__ __launch_bounds__(NTT_THREADS) void ntt_final_kernel(const NttFinalArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const Tile tile(lds_raw);
-  const int poly = blockIdx.y;
+  const int slot = blockIdx.y;
+  const int col = a.cosets ? slot / a.cosets : slot;
+  const int poly = a.first ? col : slot;
   const uint64_t* __restrict__ in = a.batch.src(poly);
-  uint64_t* __restrict__ out = a.batch.dst(poly);
+  uint64_t* __restrict__ out = a.batch.dst(col) + (a.cosets ? (uint64_t)(slot % a.cosets) * a.coset_stride : 0);
   const int log_c = a.log_c, log_r = a.log_r;
   const uint64_t k2 = blockIdx.x & ((1u << a.log_r2) - 1);
   const uint64_t k1_0 = (uint64_t)(blockIdx.x >> a.log_r2) << log_c;
@@ -254,7 +268,8 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_final_kernel(const NttFinalAr
     const int r = e & ((1 << log_r) - 1), c = e >> log_r;
     const uint64_t orow = ((k1_0 + c) << a.log_r2) + k2;
     const uint64_t idx = (orow << log_r) + r;
-    const F9 v = load_input(in, idx, !(a.first && idx >= a.n_in), kind, a.tab.from_u64);
+    F9 v = load_input(in, idx, !(a.first && idx >= a.n_in), kind, a.tab.from_u64);
+    if (a.first && a.cosets) v = mont29(v, f9_load_tw(a.prescale, ((uint64_t)(slot % a.cosets) << a.log_n) + idx));
     tile.put((int)(bitrev((uint32_t)r, log_r) << log_c) + c, v);
   }
   __syncthreads();
@@ -281,6 +296,14 @@ __global__ void ntt_table_kernel(uint32_t* out, uint64_t count, Fe base, int shi
   if (i >= count) return;
   const Fe v = fe_mul(fe_pow_u64(base, i << shift), mul);
   f9_store_tw(out, i, f9_twiddle_from_fe(v));
+}
+
+// record[(r << log_n) + j] = base^((r + 1) j), r < cosets, j < 2^log_n (base = omega_{blowup * N})
+__global__ void ntt_prescale_table_kernel(uint32_t* out, int log_n, int cosets, Fe base) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ((uint64_t)cosets << log_n)) return;
+  const uint64_t r = i >> log_n, j = i & ((1ull << log_n) - 1);
+  f9_store_tw(out, i, f9_twiddle_from_fe(fe_pow_u64(base, (r + 1) * j)));
 }
 
 // record[(k << log_inner) + q] = base^(k q) * mul, k < 2^log_r, q < 2^log_inner
