@@ -262,10 +262,11 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_final_kernel(const NttFinalAr
   const int elems = 1 << (log_r + log_c);
   const uint32_t kind = a.first ? a.batch.kind_of(poly) : (uint32_t)NTT_IN_FIELD;
 
-  // tile[bitrev(r)][c] <- row o_c = (k1_0 + c) * R2 + k2, element r.  Threads run along r so that
-  // each row is read as one contiguous stream.
+  // tile[bitrev(r)][c] <- row o_c = (k1_0 + c) * R2 + k2, element r.  Lanes run along c first:
+  // a wave reads 64 / C consecutive elements (>= one 128-byte line) of each of the C rows, and
+  // its LDS stores fall on C consecutive slots of one tile row (conflict-free).
   for (int e = threadIdx.x; e < elems; e += NTT_THREADS) {
-    const int r = e & ((1 << log_r) - 1), c = e >> log_r;
+    const int c = e & ((1 << log_c) - 1), r = e >> log_c;
     const uint64_t orow = ((k1_0 + c) << a.log_r2) + k2;
     const uint64_t idx = (orow << log_r) + r;
     F9 v = load_input(in, idx, !(a.first && idx >= a.n_in), kind, a.tab.from_u64);

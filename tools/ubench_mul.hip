@@ -62,17 +62,44 @@ __device__ __forceinline__ F9 mont29_chain32(const F9& a, const F9& b) {
   return r;
 }
 
+// V3: two products in lockstep, each a strictly sequential chain (dependent distance 2)
+__device__ __forceinline__ void mont29_x2(const F9& a1, const F9& b1, const F9& a2, const F9& b2, F9& r1, F9& r2) {
+  uint64_t acc1 = 0, acc2 = 0; uint32_t m1[9], m2[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+#pragma unroll
+    for (int i = 0; i <= k; ++i) { acc1 += (uint64_t)a1.l[i] * b1.l[k - i]; acc2 += (uint64_t)a2.l[i] * b2.l[k - i]; PIN(acc1); PIN(acc2); }
+#pragma unroll
+    for (int i = 0; i < k; ++i) { acc1 += (uint64_t)m1[i] * f9c::kp_limb29(1, k - i); acc2 += (uint64_t)m2[i] * f9c::kp_limb29(1, k - i); PIN(acc1); PIN(acc2); }
+    m1[k] = (0u - (uint32_t)acc1) & M29; m2[k] = (0u - (uint32_t)acc2) & M29;
+    acc1 += m1[k]; acc2 += m2[k]; PIN(acc1); PIN(acc2);
+    acc1 >>= 29; acc2 >>= 29;
+  }
+#pragma unroll
+  for (int k = 9; k < 17; ++k) {
+#pragma unroll
+    for (int i = k - 8; i <= 8; ++i) { acc1 += (uint64_t)a1.l[i] * b1.l[k - i]; acc2 += (uint64_t)a2.l[i] * b2.l[k - i]; PIN(acc1); PIN(acc2); }
+#pragma unroll
+    for (int i = k - 8; i <= 8; ++i) { acc1 += (uint64_t)m1[i] * f9c::kp_limb29(1, k - i); acc2 += (uint64_t)m2[i] * f9c::kp_limb29(1, k - i); PIN(acc1); PIN(acc2); }
+    r1.l[k - 9] = (uint32_t)acc1 & M29; r2.l[k - 9] = (uint32_t)acc2 & M29;
+    acc1 >>= 29; acc2 >>= 29;
+  }
+  r1.l[8] = (uint32_t)acc1; r2.l[8] = (uint32_t)acc2;
+}
+
 template <int V>
 __global__ __launch_bounds__(512) void mul_kernel(const uint32_t* tw, int reps, uint32_t* sink) {
   F9 x, w = f9_load_tw(tw, threadIdx.x & 1023);
   for (int i = 0; i < 9; ++i) x.l[i] = (threadIdx.x * 2654435761u + i * 40503u + blockIdx.x) & M29;
+  F9 x2 = x; x2.l[0] ^= 5;
   for (int r = 0; r < reps; ++r) {
+    if (V == 3) { if (r & 1) continue; F9 o1, o2; mont29_x2(x, w, x2, w, o1, o2); x = o1; x2 = o2; }
     if (V == 0) x = mont29(x, w);
     if (V == 1) x = mont29_chain(x, w);
     if (V == 2) x = mont29_chain32(x, w);
   }
   uint32_t acc = 0;
-  for (int i = 0; i < 9; ++i) acc ^= x.l[i];
+  for (int i = 0; i < 9; ++i) acc ^= x.l[i] ^ (V == 3 ? x2.l[i] : 0);
   sink[blockIdx.x * 512 + threadIdx.x] = acc;
 }
 
@@ -105,6 +132,7 @@ int main() {
     if (run<0>("compiler schedule", tw, sink, host, wps)) return 1;
     if (run<1>("single chain", tw, sink, host, wps)) return 1;
     if (run<2>("single chain + 32-bit shifts", tw, sink, host, wps)) return 1;
+    if (run<3>("two chains in lockstep", tw, sink, host, wps)) return 1;
   }
   return 0;
 }
