@@ -10,7 +10,8 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libplonk_hip.so")
+#: PLONK_HIP_LIB names another build of the same library (kernel A/B measurements)
+LIB_PATH = os.environ.get("PLONK_HIP_LIB") or os.path.join(_HERE, "libplonk_hip.so")
 
 PLK_OK = 0
 PLK_ERR_LENGTH = -1

@@ -41,6 +41,8 @@ struct NttPlan {
 struct plk_ctx {
   int device = 0;
   hipStream_t stream = nullptr;  // used by the host entry points
+  hipStream_t aux = nullptr;     // side stream of plk_round23: the grand-product chain runs beside the transforms
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::map<std::pair<int, int>, NttPlan> plans;  // (log_n, inverse)
   std::map<std::string, DevBuf> ws;              // grow-only workspace slots
   GpStatus* status_dev = nullptr;
@@ -225,7 +227,7 @@ int get_plan(plk_ctx* ctx, int log_n, bool inverse, hipStream_t s, NttPlan** out
 // batch <= NTT_MAX_BATCH) or as one base pointer plus a stride in elements.
 int launch_ntt(plk_ctx* ctx, hipStream_t s, const uint64_t* const* in, const uint32_t* kinds, size_t batch,
                size_t n_in, size_t N, bool inverse, uint64_t* const* out, size_t stride_in = 0, size_t stride_out = 0,
-               int cosets = 0) {
+               int cosets = 0, const char* tmp_slot = "ntt_tmp") {
   int log_n, rc;
   if ((rc = check_domain(ctx, N, &log_n))) return rc;
   if (n_in > N) return fail(ctx, PLK_ERR_LENGTH, "more input elements than domain points");
@@ -268,7 +270,7 @@ int launch_ntt(plk_ctx* ctx, hipStream_t s, const uint64_t* const* in, const uin
   uint64_t* tmp = nullptr;
   if (plan->npass > 1) {
     void* p;
-    if ((rc = ws_get(ctx, "ntt_tmp", slots * N * ELEM, &p))) return rc;
+    if ((rc = ws_get(ctx, tmp_slot, slots * N * ELEM, &p))) return rc;
     tmp = (uint64_t*)p;
   }
   const size_t lds_bytes = NTT_LDS_BYTES;
@@ -277,8 +279,9 @@ int launch_ntt(plk_ctx* ctx, hipStream_t s, const uint64_t* const* in, const uin
   // attributed in equal shares to its P launches
   // (an n -> 4n extension done as three coset transforms is credited the extension's 160 n bytes)
   const double alg_share = (cosets ? 160.0 * (double)N : 32.0 * (double)n_in + 32.0 * (double)N) * (double)batch / P;
-  const std::string tag = cosets ? "/lde" + std::to_string(log_n) + "to" + std::to_string(log_n + 2)
-                                 : std::string(inverse ? "/intt" : "/ntt") + std::to_string(log_n) + (n_in < N ? "lde" : "");
+  const std::string tag = (cosets ? "/lde" + std::to_string(log_n) + "to" + std::to_string(log_n + 2)
+                                  : std::string(inverse ? "/intt" : "/ntt") + std::to_string(log_n) + (n_in < N ? "lde" : "")) +
+                          (std::string(tmp_slot) == "ntt_tmp" ? "" : "/side");
   auto from_user = [&](NttBatch& b) { for (int i = 0; i < NTT_MAX_BATCH; ++i) { b.in[i] = user.in[i]; b.kind[i] = user.kind[i]; } b.stride_in = user.stride_in; };
   auto to_user = [&](NttBatch& b) { for (int i = 0; i < NTT_MAX_BATCH; ++i) b.out[i] = user.out[i]; b.stride_out = user.stride_out; };
   auto from_tmp = [&](NttBatch& b) { b.in[0] = tmp; b.stride_in = (uint64_t)N * 4; b.kind[0] = NTT_IN_FIELD; };
@@ -443,24 +446,33 @@ int launch_round23(plk_ctx* ctx, hipStream_t s, const uint64_t* const wires[4], 
   uint64_t* eval = (uint64_t*)eval_p;
   uint64_t* z = z_out ? z_out : (uint64_t*)z_p;
 
-  if ((rc = launch_grand_product(ctx, s, wires, sigma, n, beta, gamma, z))) return rc;
-
-  // interpolation of every column present (rows 3 and 6 of the path): one batched inverse transform
   const uint64_t* in[NCOL]; uint64_t* out[NCOL]; uint32_t kinds[NCOL]; int col_of[NCOL]; size_t m = 0;
   auto col_coef = [&](int c) { return coef + (size_t)c * n * 4; };
   auto col_eval = [&](int c) { return eval + (size_t)c * N * 4; };
-  for (int k = 0; k < 4; ++k) { in[m] = wires[k]; kinds[m] = NTT_IN_FIELD; col_of[m] = k; ++m; }
-  for (int k = 0; k < 9; ++k) if (sel && sel[k]) { in[m] = sel[k]; kinds[m] = NTT_IN_FIELD; col_of[m] = 4 + k; ++m; }
-  for (int k = 0; k < 4; ++k) { in[m] = sigma[k]; kinds[m] = NTT_IN_U64; col_of[m] = 13 + k; ++m; }
-  in[m] = z; kinds[m] = NTT_IN_FIELD; col_of[m] = 17; ++m;
-  for (size_t b = 0; b < m; ++b) out[b] = col_coef(col_of[b]);
-  if ((rc = launch_ntt(ctx, s, in, kinds, m, n, n, true, out))) return rc;
 
   if (N == 4 * n && log_n >= 2 && log_n + 2 <= Field::TWO_ADICITY) {
     // The 4n-point domain is four cosets of the trace domain.  On coset 0 every column IS its
     // table (interpolation followed by evaluation at the same points is the identity), so only
     // cosets 1..3 are computed: three prescaled n-point transforms per column, kept coset-major.
     auto col_cos = [&](int c) { return eval + (size_t)c * 3 * n * 4; };   // planes 1..3 of column c
+    // Side stream: grand product -> Z interpolation -> Z cosets.  Its kernels are gather-, latency-
+    // and launch-bound; they run beside the 17 other columns' transforms, which are VALU-bound.
+    hipStream_t sa = ctx->aux;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, s));
+    HIP_TRY(ctx, hipStreamWaitEvent(sa, ctx->ev_fork, 0));
+    if ((rc = launch_grand_product(ctx, sa, wires, sigma, n, beta, gamma, z))) return rc;
+    {
+      const uint64_t* zin[1] = {z}; uint64_t* zc[1] = {col_coef(17)}; uint64_t* ze[1] = {col_cos(17)};
+      if ((rc = launch_ntt(ctx, sa, zin, nullptr, 1, n, n, true, zc, 0, 0, 0, "ntt_tmp_aux"))) return rc;
+      const uint64_t* zci[1] = {col_coef(17)};
+      if ((rc = launch_ntt(ctx, sa, zci, nullptr, 1, n, n, false, ze, 0, 0, 3, "ntt_tmp_aux"))) return rc;
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_join, sa));
+    for (int k = 0; k < 4; ++k) { in[m] = wires[k]; kinds[m] = NTT_IN_FIELD; col_of[m] = k; ++m; }
+    for (int k = 0; k < 9; ++k) if (sel && sel[k]) { in[m] = sel[k]; kinds[m] = NTT_IN_FIELD; col_of[m] = 4 + k; ++m; }
+    for (int k = 0; k < 4; ++k) { in[m] = sigma[k]; kinds[m] = NTT_IN_U64; col_of[m] = 13 + k; ++m; }
+    for (size_t b = 0; b < m; ++b) out[b] = col_coef(col_of[b]);
+    if ((rc = launch_ntt(ctx, s, in, kinds, m, n, n, true, out))) return rc;
     for (size_t b = 0; b < m; ++b) { in[b] = col_coef(col_of[b]); out[b] = col_cos(col_of[b]); }
     if ((rc = launch_ntt(ctx, s, in, nullptr, m, n, n, false, out, 0, 0, 3))) return rc;
     if (gate_out) {
@@ -473,6 +485,7 @@ int launch_round23(plk_ctx* ctx, hipStream_t s, const uint64_t* const wires[4], 
                          (uint64_t)n, gate_out);
       HIP_TRY(ctx, hipGetLastError());
     }
+    HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
     if (perm_out) {
       const Fe fb = fe_from_limbs64(beta), fg = fe_from_limbs64(gamma);
       PermColsCoset pc{};
@@ -485,6 +498,16 @@ int launch_round23(plk_ctx* ctx, hipStream_t s, const uint64_t* const wires[4], 
     }
     return PLK_OK;
   }
+
+  if ((rc = launch_grand_product(ctx, s, wires, sigma, n, beta, gamma, z))) return rc;
+
+  // interpolation of every column present (rows 3 and 6 of the path): one batched inverse transform
+  for (int k = 0; k < 4; ++k) { in[m] = wires[k]; kinds[m] = NTT_IN_FIELD; col_of[m] = k; ++m; }
+  for (int k = 0; k < 9; ++k) if (sel && sel[k]) { in[m] = sel[k]; kinds[m] = NTT_IN_FIELD; col_of[m] = 4 + k; ++m; }
+  for (int k = 0; k < 4; ++k) { in[m] = sigma[k]; kinds[m] = NTT_IN_U64; col_of[m] = 13 + k; ++m; }
+  in[m] = z; kinds[m] = NTT_IN_FIELD; col_of[m] = 17; ++m;
+  for (size_t b = 0; b < m; ++b) out[b] = col_coef(col_of[b]);
+  if ((rc = launch_ntt(ctx, s, in, kinds, m, n, n, true, out))) return rc;
 
   // evaluation of every coefficient vector on the N-point domain (wires once, shared by both checks)
   for (size_t b = 0; b < m; ++b) { in[b] = col_coef(col_of[b]); out[b] = col_eval(col_of[b]); }
@@ -576,6 +599,9 @@ int plk_ctx_create(int device, plk_ctx** out) {
   } while (0)
   CTX_TRY(hipSetDevice(device));
   CTX_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  CTX_TRY(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
+  CTX_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+  CTX_TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
   CTX_TRY(hipMalloc((void**)&ctx->status_dev, sizeof(GpStatus)));
   CTX_TRY(hipHostMalloc((void**)&ctx->status_host, sizeof(GpStatus)));
   CTX_TRY(hipMemset(ctx->status_dev, 0xff, sizeof(GpStatus)));
@@ -600,6 +626,9 @@ void plk_ctx_destroy(plk_ctx* ctx) {
   for (auto& e : ctx->event_pool) (void)hipEventDestroy(e);
   if (ctx->status_dev) (void)hipFree(ctx->status_dev);
   if (ctx->status_host) (void)hipHostFree(ctx->status_host);
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+  if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

@@ -151,6 +151,49 @@ __device__ __forceinline__ F9 mont29(const F9& a, const F9& b) {
   return r;
 }
 
+// Two independent products in lockstep.  Each accumulation is kept a strictly sequential chain
+// (the empty asm stops the compiler from splitting it into partial sums that must be merged by
+// 64-bit adds); interleaving the two chains keeps dependent multiply-adds two issues apart.
+#define PLK_PIN(x) asm volatile("" : "+v"(x))
+__device__ __forceinline__ void mont29_x2(const F9& a1, const F9& b1, const F9& a2, const F9& b2, F9& r1, F9& r2) {
+  uint64_t acc1 = 0, acc2 = 0;
+  uint32_t m1[9], m2[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+#pragma unroll
+    for (int i = 0; i <= k; ++i) {
+      acc1 += (uint64_t)a1.l[i] * b1.l[k - i]; acc2 += (uint64_t)a2.l[i] * b2.l[k - i];
+      PLK_PIN(acc1); PLK_PIN(acc2);
+    }
+#pragma unroll
+    for (int i = 0; i < k; ++i) {
+      acc1 += (uint64_t)m1[i] * f9c::kp_limb29(1, k - i); acc2 += (uint64_t)m2[i] * f9c::kp_limb29(1, k - i);
+      PLK_PIN(acc1); PLK_PIN(acc2);
+    }
+    m1[k] = (0u - (uint32_t)acc1) & M29; m2[k] = (0u - (uint32_t)acc2) & M29;
+    acc1 += m1[k]; acc2 += m2[k];
+    PLK_PIN(acc1); PLK_PIN(acc2);
+    acc1 >>= 29; acc2 >>= 29;
+  }
+#pragma unroll
+  for (int k = 9; k < 17; ++k) {
+#pragma unroll
+    for (int i = k - 8; i <= 8; ++i) {
+      acc1 += (uint64_t)a1.l[i] * b1.l[k - i]; acc2 += (uint64_t)a2.l[i] * b2.l[k - i];
+      PLK_PIN(acc1); PLK_PIN(acc2);
+    }
+#pragma unroll
+    for (int i = k - 8; i <= 8; ++i) {
+      acc1 += (uint64_t)m1[i] * f9c::kp_limb29(1, k - i); acc2 += (uint64_t)m2[i] * f9c::kp_limb29(1, k - i);
+      PLK_PIN(acc1); PLK_PIN(acc2);
+    }
+    r1.l[k - 9] = (uint32_t)acc1 & M29; r2.l[k - 9] = (uint32_t)acc2 & M29;
+    acc1 >>= 29; acc2 >>= 29;
+  }
+  r1.l[8] = (uint32_t)acc1; r2.l[8] = (uint32_t)acc2;
+}
+#undef PLK_PIN
+
 __device__ __forceinline__ F9 f9_add(const F9& a, const F9& b) {
   F9 r;
 #pragma unroll

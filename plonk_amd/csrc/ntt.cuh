@@ -146,19 +146,33 @@ __device__ __forceinline__ void tile_dit(const Tile& t, int log_r, int log_c, co
   for (int lh = first; lh < log_r; ++lh) {
     const int h = 1 << lh;
     const bool renorm = ((lh - first) & 1) != 0;   // after every second stage
-    for (int b = threadIdx.x; b < total; b += NTT_THREADS) {
-      const int c = b & ((1 << log_c) - 1);
-      const int q = b >> log_c;
-      const int j = q & (h - 1);
-      const int i0 = ((q >> lh) << (lh + 1)) + j;
-      const int e0 = (i0 << log_c) + c, e1 = ((i0 + h) << log_c) + c;
-      const F9 x = t.get(e0);
-      F9 y = t.get(e1);
-      if (lh > 0) y = mont29(y, tw_lds ? ltw.get(j << (log_r - 1 - lh)) : f9_load_tw(master, (size_t)j << (NTT_MASTER_LOG - 1 - lh)));
-      F9 u = f9_add(x, y), v = f9_sub_q2(x, y);
-      if (renorm) { f9_normalize(u); f9_normalize(v); }
-      t.put(e0, u);
-      t.put(e1, v);
+    // two butterflies per thread and iteration, their products interleaved (mont29_x2)
+    for (int b = threadIdx.x; b < total; b += 2 * NTT_THREADS) {
+      const int bb[2] = {b, b + NTT_THREADS};
+      const bool second = bb[1] < total;
+      int e0[2], e1[2], jj[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int bu = (u == 1 && !second) ? b : bb[u];
+        const int c = bu & ((1 << log_c) - 1);
+        const int q = bu >> log_c;
+        jj[u] = q & (h - 1);
+        const int i0 = ((q >> lh) << (lh + 1)) + jj[u];
+        e0[u] = (i0 << log_c) + c; e1[u] = ((i0 + h) << log_c) + c;
+      }
+      const F9 xa = t.get(e0[0]), xb = t.get(e0[1]);
+      F9 ya = t.get(e1[0]), yb = t.get(e1[1]);
+      if (lh > 0) {
+        const F9 wa = tw_lds ? ltw.get(jj[0] << (log_r - 1 - lh)) : f9_load_tw(master, (size_t)jj[0] << (NTT_MASTER_LOG - 1 - lh));
+        const F9 wb = tw_lds ? ltw.get(jj[1] << (log_r - 1 - lh)) : f9_load_tw(master, (size_t)jj[1] << (NTT_MASTER_LOG - 1 - lh));
+        F9 ta, tb;
+        mont29_x2(ya, wa, yb, wb, ta, tb);
+        ya = ta; yb = tb;
+      }
+      F9 ua = f9_add(xa, ya), va = f9_sub_q2(xa, ya), ub = f9_add(xb, yb), vb = f9_sub_q2(xb, yb);
+      if (renorm) { f9_normalize(ua); f9_normalize(va); f9_normalize(ub); f9_normalize(vb); }
+      t.put(e0[0], ua); t.put(e1[0], va);
+      if (second) { t.put(e0[1], ub); t.put(e1[1], vb); }
     }
     __syncthreads();
   }
