@@ -305,9 +305,11 @@ int launch_ntt(plk_ctx* ctx, hipStream_t s, const uint64_t* const* in, const uin
     a.prescale = prescale;
     if (p == 0) from_user(a.batch); else from_tmp(a.batch);
     to_tmp(a.batch);
-    const unsigned tiles = 1u << (log_n - lr - a.log_c);
+    const uint64_t tiles = 1ull << (log_n - lr - a.log_c);
+    if (tiles * slots > 0x7fffffffull) return fail(ctx, PLK_ERR_ARG, "transform batch too large for one launch");
+    a.slots = (uint32_t)slots;
     ProfScope ps(ctx, s, "ntt_pass_kernel" + tag + "/p" + std::to_string(p), alg_share);
-    hipLaunchKernelGGL(ntt_pass_kernel, dim3(tiles, (unsigned)slots), dim3(NTT_THREADS), lds_bytes, s, a);
+    hipLaunchKernelGGL(ntt_pass_kernel, dim3((unsigned)(tiles * slots)), dim3(NTT_THREADS), lds_bytes, s, a);
     HIP_TRY(ctx, hipGetLastError());
   }
   {

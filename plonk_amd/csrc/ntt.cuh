@@ -202,20 +202,31 @@ struct NttPassArgs {
   // prescale[r * N + j] = omega_M^((r+1) j) before the transform
   int cosets;
   const uint32_t* prescale;
+  uint32_t slots;    // transforms in this launch; the grid is 1-D with tiles * slots workgroups
 };
 
 // Non-final pass: digit transform + inter-pass twiddle; out may alias in when !first.
+//
+// Workgroup order: hardware hands consecutive workgroup ids to the 8 XCDs in turn, each with its
+// own L2.  The id is first un-swizzled so that one XCD walks a contiguous range of logical ids,
+// and a logical id is tile-major / slot-minor: the slots of one tile position (all columns and
+// cosets) run on one XCD at about the same time, so the inter-pass twiddle and prescale records
+// of that position, and in coset mode the input tile shared by a column's cosets, come from L2
+// instead of once per slot from memory.
 __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const NttPassArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const Tile tile(lds_raw);
-  const int slot = blockIdx.y;
+  uint32_t wg = blockIdx.x;
+  if ((gridDim.x & 7u) == 0) wg = (wg & 7u) * (gridDim.x >> 3) + (wg >> 3);
+  const uint32_t tile_id = wg / a.slots;
+  const int slot = (int)(wg - tile_id * a.slots);
   const int poly = (a.first && a.cosets) ? slot / a.cosets : slot;
   const uint64_t* __restrict__ in = a.batch.src(poly);
   uint64_t* __restrict__ out = a.batch.dst(slot);
   const int log_c = a.log_c, log_r = a.log_r, log_inner = a.log_inner;
   const int tiles_per_block = 1 << (log_inner - log_c);       // tiles per value of the outer digits
-  const uint64_t o = blockIdx.x >> (log_inner - log_c);
-  const uint64_t q0 = (uint64_t)(blockIdx.x & (tiles_per_block - 1)) << log_c;
+  const uint64_t o = tile_id >> (log_inner - log_c);
+  const uint64_t q0 = (uint64_t)(tile_id & (tiles_per_block - 1)) << log_c;
   const uint64_t base = (o << (log_r + log_inner)) + q0;
   const int elems = 1 << (log_r + log_c);
   const uint32_t kind = a.first ? a.batch.kind_of(poly) : (uint32_t)NTT_IN_FIELD;
@@ -265,7 +276,7 @@ struct NttFinalArgs {
 __global__ __launch_bounds__(NTT_THREADS) void ntt_final_kernel(const NttFinalArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const Tile tile(lds_raw);
-  const int slot = blockIdx.y;
+  const int slot = blockIdx.y;   // slots share nothing here, so the plain 2-D order is kept
   const int col = a.cosets ? slot / a.cosets : slot;
   const int poly = a.first ? col : slot;
   const uint64_t* __restrict__ in = a.batch.src(poly);

@@ -5,7 +5,7 @@
                              counters, VALU activity
   <tag>_pmc_summary.json     label -> hbm_bytes_per_launch (read by bench.py for roofline.traffic)
 
-Dispatches of one round-2+3 step arrive in a fixed order, which maps them to bench.py's labels.
+Dispatches are mapped to bench.py's labels by kernel name, grid size and order (see BY_GRID).
 HBM bytes follow the gfx950 rule: FETCH_SIZE and WRITE_SIZE are in KiB, FETCH_SIZE counts half the
 bytes of wide coalesced reads, so bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.
 """
@@ -17,26 +17,53 @@ import shutil
 import sys
 from collections import OrderedDict, defaultdict
 
-STEP = ["gp_terms_kernel", "gp_block_scan_kernel", "gp_finish_kernel",
-        "ntt_pass_kernel/intt20/p0", "ntt_pass_kernel/intt20/p1", "ntt_final_kernel/intt20",
-        "ntt_pass_kernel/ntt22lde/p0", "ntt_pass_kernel/ntt22lde/p1", "ntt_final_kernel/ntt22lde",
-        "gate_constraint_kernel", "perm_constraint_kernel"]
+# Labels of one round-2+3 step.  The grand product and the Z transforms run on a side stream, so
+# dispatch order interleaves between steps; launches are told apart by kernel name and grid size
+# (side-stream transforms carry 1 column, main-stream ones 17; an extension has 3 cosets per column)
+# and, for the two passes of one transform, by their order within that (name, grid) class.
+BY_GRID = {
+    "gp_terms_kernel": [["gp_terms_kernel"]],
+    "gp_block_scan_kernel": [["gp_block_scan_kernel"]],
+    "gp_finish_kernel": [["gp_finish_kernel"]],
+    "ntt_pass_kernel": [["ntt_pass_kernel/intt20/side/p0", "ntt_pass_kernel/intt20/side/p1"],
+                        ["ntt_pass_kernel/lde20to22/side/p0", "ntt_pass_kernel/lde20to22/side/p1"],
+                        ["ntt_pass_kernel/intt20/p0", "ntt_pass_kernel/intt20/p1"],
+                        ["ntt_pass_kernel/lde20to22/p0", "ntt_pass_kernel/lde20to22/p1"]],
+    "ntt_final_kernel": [["ntt_final_kernel/intt20/side"], ["ntt_final_kernel/lde20to22/side"],
+                         ["ntt_final_kernel/intt20"], ["ntt_final_kernel/lde20to22"]],
+    "gate_constraint_coset_kernel": [["gate_constraint_coset_kernel"]],
+    "perm_constraint_coset_kernel": [["perm_constraint_coset_kernel"]],
+}
+STEP = [l for groups in BY_GRID.values() for g in groups for l in g]
 
 
 def short(name):
     return name.split("(")[0].replace("plk::", "")
 
 
+def grid_of(r):
+    if "Grid_Size" in r:  # counter-collection rows carry the flattened size
+        return int(r["Grid_Size"])
+    return int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
+
+
 def labelled(rows, name_key):
-    """yield (label, row) for the dispatches that belong to round-2+3 steps, in order."""
+    """yield (label, row) for the dispatches that belong to round-2+3 steps."""
     rows = [r for r in rows if r[name_key].startswith("plk::") and "table_kernel" not in r[name_key]]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    i = 0
+    grids = defaultdict(set)
     for r in rows:
-        want = STEP[i % len(STEP)]
-        assert short(r[name_key]) == want.split("/")[0], (short(r[name_key]), want)
-        yield want, r
-        i += 1
+        grids[short(r[name_key])].add(grid_of(r))
+    seen = defaultdict(int)
+    for r in rows:
+        name = short(r[name_key])
+        groups = BY_GRID[name]
+        order = sorted(grids[name])
+        assert len(order) == len(groups), (name, order)
+        labels = groups[order.index(grid_of(r))]
+        k = (name, grid_of(r))
+        yield labels[seen[k] % len(labels)], r
+        seen[k] += 1
 
 
 def main():
