@@ -104,13 +104,18 @@ def main():
             rec["hbm_GBps"] = rec["hbm_bytes_per_launch"] / (rec["avg_ms"] * 1e-3) / 1e9
             pmc[label] = {"hbm_bytes_per_launch": rec["hbm_bytes_per_launch"], "fetch_kib_raw": c["FETCH_SIZE"],
                           "write_kib_raw": c["WRITE_SIZE"]}
-        if "SQ_BUSY_CYCLES" in c and "SQ_ACTIVE_INST_VALU" in c:
-            # SQ_* cycle counters are summed over shader engines / counted in quad-cycles: report ratios only
-            rec["valu_active_over_wave_cycles"] = c["SQ_ACTIVE_INST_VALU"] / max(c.get("SQ_WAVE_CYCLES", 0), 1)
+        if "SQ_INSTS_VALU" in c and "SQ_WAVES" in c:
+            rec["valu_insts_per_launch"] = c["SQ_INSTS_VALU"]          # wave-level instructions, all SIMDs
+            rec["valu_insts_per_wave"] = c["SQ_INSTS_VALU"] / max(c["SQ_WAVES"], 1)
+            rec["waves"] = c["SQ_WAVES"]
+            # SQ_WAVE_CYCLES / SQ_WAIT_* count quad-cycles summed over waves: ratios only
             rec["wait_any_over_wave_cycles"] = c.get("SQ_WAIT_ANY", 0) / max(c.get("SQ_WAVE_CYCLES", 0), 1)
-            rec["wait_inst_any_over_wave_cycles"] = c.get("SQ_WAIT_INST_ANY", 0) / max(c.get("SQ_WAVE_CYCLES", 0), 1)
-            rec["valu_insts_per_wave"] = c.get("SQ_INSTS_VALU", 0) / max(c.get("SQ_WAVES", 0), 1)
-            rec["waves"] = c.get("SQ_WAVES", 0)
+            if "GRBM_GUI_ACTIVE" in c:
+                # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs issue the launch's VALU instructions
+                rec["cycles_per_valu_inst_per_simd"] = (c["GRBM_GUI_ACTIVE"] / 8) * 1024 / max(c["SQ_INSTS_VALU"], 1)
+            if label in pmc:
+                pmc[label]["valu_insts_per_launch"] = rec["valu_insts_per_launch"]
+                pmc[label]["cycles_per_valu_inst_per_simd"] = rec.get("cycles_per_valu_inst_per_simd")
         for k in ("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "GRBM_GUI_ACTIVE", "SQ_ACTIVE_INST_LDS"):
             if k in c:
                 rec[k] = c[k]
@@ -122,12 +127,18 @@ def main():
     json.dump(pmc, open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w"), indent=1)
     with open(os.path.join(dst, f"{tag}_by_label.md"), "w") as f:
         f.write(f"# rocprofv3 summary `{tag}` — `python3 bench.py --steps 3 --warmup 1` (n = 2^20, N = 2^22, 18 columns)\n\n")
-        f.write("| label | launches | avg ms | grid | VGPR | LDS B | HBM GB/launch (PMC) | HBM GB/s | VALU-active / wave-cycles | wait-any / wave-cycles | eff. clock GHz |\n|---|---|---|---|---|---|---|---|---|---|---|\n")
+        f.write("| label | launches | avg ms | grid | VGPR | LDS B | HBM GB/launch (PMC) | HBM GB/s | VALU wave-instr / launch | cycles per VALU instr per SIMD | wait-any / wave-cycles | eff. clock GHz |\n|---|---|---|---|---|---|---|---|---|---|---|---|\n")
         for r in out:
             f.write(f'| {r["label"]} | {r["launches"]} | {r["avg_ms"]:.3f} | {r["grid"]} | {r["vgpr"]} | {r["lds"]} | '
                     f'{r.get("hbm_bytes_per_launch", 0) / 1e9:.3f} | {r.get("hbm_GBps", 0):.0f} | '
-                    f'{r.get("valu_active_over_wave_cycles", 0):.3f} | {r.get("wait_any_over_wave_cycles", 0):.3f} | {r.get("eff_clock_GHz", 0):.2f} |\n')
-        f.write("\nHBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950: FETCH_SIZE counts half of a wide coalesced read).\n")
+                    f'{r.get("valu_insts_per_launch", 0):.3g} | {r.get("cycles_per_valu_inst_per_simd", 0):.2f} | '
+                    f'{r.get("wait_any_over_wave_cycles", 0):.3f} | {r.get("eff_clock_GHz", 0):.2f} |\n')
+        f.write("\nHBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950: FETCH_SIZE counts half of a wide coalesced read).\n"
+                "Cycles per VALU instruction per SIMD = (GRBM_GUI_ACTIVE / 8 XCDs) x 1024 SIMDs / SQ_INSTS_VALU: the launch's duration in\n"
+                "shader cycles divided by the wave-level vector instructions each SIMD issued.  The transform kernels' instruction mix\n"
+                "(about two thirds v_mad_u64_u32 at ~5 cycles, the rest at ~2.6; tools/ubench_valu.hip) costs ~4.2 cycles per instruction,\n"
+                "so a value near 4.3 means the vector ALUs are issuing back to back: those kernels are bound by integer multiply-add issue,\n"
+                "not by HBM.  Side-stream launches (`/side`, grand product) overlap main-stream kernels, so their own figures are diluted.\n")
     print(open(os.path.join(dst, f"{tag}_by_label.md")).read())
 
 
