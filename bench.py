@@ -70,17 +70,18 @@ def cpu_baseline(log_n_full: int, blowup: int, sample_log_n: int):
     }
 
 
-def pmc_traffic(label: str):
-    """HBM bytes per launch of the dominant kernel from a committed rocprofv3 --pmc summary, if any."""
+def pmc_record(label: str):
+    """Counter figures of one kernel label from the newest committed rocprofv3 --pmc summary, if any:
+    (record, file name); record has hbm_bytes_per_launch and the VALU issue figures."""
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.json")), reverse=True):
         try:
             with open(path) as f:
                 data = json.load(f)
             if label in data:
-                return data[label]["hbm_bytes_per_launch"], os.path.basename(path)
+                return data[label], os.path.basename(path)
         except Exception:
             continue
-    return None, None
+    return {}, None
 
 
 def timed(fn, steps, warmup, dist, device):
@@ -223,13 +224,17 @@ def main():
             per_launch_ms = dom["total_ms"] / dom["launches"]
             per_launch_bytes = dom["alg_bytes"] / dom["launches"]
             achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
-            traffic, src = pmc_traffic(dom["label"])
+            pmc, src = pmc_record(dom["label"])
             roofline = {"bound": "hbm", "kernel": dom["label"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc.get("hbm_bytes_per_launch"),
                         "traffic_source": src, "avg_launch_ms": round(per_launch_ms, 4),
                         "alg_bytes_per_launch": per_launch_bytes,
+                        "valu_cycles_per_inst_per_simd": pmc.get("cycles_per_valu_inst_per_simd"),
                         "note": "a transform of N points over B columns is 64*N*B algorithmic bytes (160*n*B for an n -> 4n "
-                                "extension); each of its P launches is credited 1/P of that"}
+                                "extension); each of its P launches is credited 1/P of that. The nominal bound is HBM, but the "
+                                "256-bit modular products keep the vector ALUs issuing back to back (see "
+                                "valu_cycles_per_inst_per_simd against the ~4.2 cycles this instruction mix costs): the kernel "
+                                "is bound by integer multiply-add issue"}
         # whole-transform throughput of the extension (all launches of the N-point forward transform)
         lde = [r for r in prof if f"/ntt{args.log_n + args.blowup.bit_length() - 1}" in r["label"] or "/lde" in r["label"]]
         ntt = None

@@ -82,7 +82,12 @@ def main():
                        "sgpr": r["SGPR_Count"], "lds": r["LDS_Block_Size"], "scratch": r["Scratch_Size"]}
     counters = defaultdict(lambda: defaultdict(float))
     ncount = defaultdict(lambda: defaultdict(int))
+    newest = {}   # one file per pass directory: merged output of repeated runs may hold older ones
     for path in glob.glob(os.path.join(src, "pmc_*", "**", "*_counter_collection.csv"), recursive=True):
+        d = os.path.dirname(path)
+        if d not in newest or os.path.getmtime(path) > os.path.getmtime(newest[d]):
+            newest[d] = path
+    for path in newest.values():
         rows = list(csv.DictReader(open(path)))
         names = sorted(set(r["Counter_Name"] for r in rows))
         for cname in names:
