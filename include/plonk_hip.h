@@ -119,6 +119,22 @@ int plk_round23(plk_ctx* ctx, const uint64_t* const wires[PLK_NUM_WIRES], const 
                 const uint64_t beta[4], const uint64_t gamma[4], size_t z_shift,
                 uint64_t* z_out, uint64_t* gate_out, uint64_t* perm_out);
 
+/* ---- the step before the path: the permutation table ------------------------------------- */
+
+/* build_permutation_trace + build_permutation_table — src/permutation_polynomial.rs:18-39, :79-202,
+ * over group_wire_positions_by_node_id (src/execution_trace.rs:191-197) and OffsetTable::to_index
+ * (src/offset_table.rs:61-64), with the trace flattened to one node id per wire and global row:
+ * node_ids[w][j] = `node_id` of the value on wire w (0, 1, 2 = inputs, 3 = output) of global row j
+ * (rows numbered as the offset table numbers them), or PLK_NO_WIRE where the row's operation does
+ * not use that wire.  All positions carrying one node id are linked into a cycle in ascending
+ * (row, wire) order — the order collect_wire_positions (src/execution_trace.rs:109-187) produces —
+ * and sigma_out[w][j] = the global ROW of the position after (j, w) in its cycle (the wire of that
+ * next position is dropped, as to_index drops it); a node id seen once, and an unused wire, map to
+ * their own row (:24-27, :121-122, :157).  Any n >= 0, not only powers of two. */
+#define PLK_NO_WIRE UINT64_MAX
+int plk_sigma_table(plk_ctx* ctx, const uint64_t* const node_ids[PLK_NUM_WIRES], size_t n,
+                    uint64_t* const sigma_out[PLK_NUM_WIRES]);
+
 /* ---- device entry points (same arithmetic, device pointers, asynchronous) ---------------- */
 
 /* `batch` transforms of size N in one set of launches.  in[b] holds n_in valid elements
@@ -141,6 +157,10 @@ int plk_dev_mul(plk_ctx* ctx, void* stream, const uint64_t* a, const uint64_t* b
  * No counterpart in the reference (ark-poly runs one shared-memory FFT). */
 int plk_dev_twiddle_block(plk_ctx* ctx, void* stream, size_t N, int inverse, int scale_by_inverse_n, size_t rows, size_t cols,
                           size_t row0, size_t col0, uint64_t* out);
+
+/* plk_sigma_table on device columns (n uint64_t each) */
+int plk_dev_sigma_table(plk_ctx* ctx, void* stream, const uint64_t* const node_ids[PLK_NUM_WIRES], size_t n,
+                        uint64_t* const sigma_out[PLK_NUM_WIRES]);
 
 int plk_dev_grand_product(plk_ctx* ctx, void* stream, const uint64_t* const wires[PLK_NUM_WIRES],
                           const uint64_t* const sigma[PLK_NUM_WIRES], size_t n,

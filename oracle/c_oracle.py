@@ -160,3 +160,14 @@ def num_threads():
 
 def set_num_threads(t):
     lib().orc_set_num_threads(C.c_int(t))
+
+
+def sigma_table(node_ids):
+    """orc_sigma_table: four `(n,) uint64` node-id columns -> four `(n,) uint64` sigma columns."""
+    cols = [_c(a) for a in node_ids]
+    n = cols[0].shape[0]
+    out = [np.empty((n,), dtype=np.uint64) for _ in range(4)]
+    rc = lib().orc_sigma_table(_tab(cols), C.c_size_t(n), _tab(out))
+    if rc:
+        raise OracleError(rc)
+    return out

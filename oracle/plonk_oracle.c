@@ -327,6 +327,37 @@ int orc_round23(const u64* const wires[4], const u64* const sel[9], const u64* c
   return rc;
 }
 
+/* ---- the permutation (sigma) table from flattened node ids ----
+ * build_permutation_trace + build_permutation_table, src/permutation_polynomial.rs:18-39, :79-202:
+ * positions of one node id, in ascending (row, wire) order (collect_wire_positions,
+ * src/execution_trace.rs:109-187), form a cycle; sigma[w][j] = row of the next position
+ * (OffsetTable::to_index keeps the row only, src/offset_table.rs:61-64); unused wires (node id
+ * UINT64_MAX) and single positions map to their own row. */
+typedef struct { u64 node; u64 pos; } sig_pair;
+static int sig_cmp(const void* a, const void* b) {
+  const sig_pair *x = (const sig_pair*)a, *y = (const sig_pair*)b;
+  if (x->node != y->node) return x->node < y->node ? -1 : 1;
+  return x->pos < y->pos ? -1 : (x->pos > y->pos);
+}
+int orc_sigma_table(const u64* const node_ids[4], size_t n, u64* const sigma_out[4]) {
+  sig_pair* v = (sig_pair*)malloc((4 * n + 1) * sizeof(sig_pair));
+  if (!v) return -8;
+  size_t m = 0;
+  for (size_t j = 0; j < n; ++j)
+    for (int w = 0; w < 4; ++w) {
+      sigma_out[w][j] = j;
+      if (node_ids[w][j] != UINT64_MAX) { v[m].node = node_ids[w][j]; v[m].pos = 4 * j + w; ++m; }
+    }
+  qsort(v, m, sizeof(sig_pair), sig_cmp);
+  for (size_t i = 0, first = 0; i < m; ++i) {
+    if (i > 0 && v[i].node != v[i - 1].node) first = i;
+    const size_t next = (i + 1 < m && v[i + 1].node == v[i].node) ? i + 1 : first;
+    sigma_out[v[i].pos & 3][v[i].pos >> 2] = v[next].pos >> 2;
+  }
+  free(v);
+  return 0;
+}
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

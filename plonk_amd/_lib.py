@@ -28,6 +28,7 @@ NUM_SELECTORS = 9
 MAX_BATCH = 24
 INPUT_FIELD = 0
 INPUT_U64 = 1
+NO_WIRE = (1 << 64) - 1
 
 u64p = C.POINTER(C.c_uint64)
 u64pp = C.POINTER(u64p)
@@ -51,6 +52,8 @@ SIGNATURES = {
     "plk_perm_polys": (C.c_int, [C.c_void_p, u64pp, u64pp, C.c_size_t, C.c_size_t, u64p, u64p, u64pp, u64p, u64p]),
     "plk_perm_constraints": (C.c_int, [C.c_void_p, u64p, u64pp, u64pp, C.c_size_t, C.c_size_t, u64p, u64p, C.c_size_t, u64p]),
     "plk_round23": (C.c_int, [C.c_void_p, u64pp, u64pp, u64pp, C.c_size_t, C.c_size_t, u64p, u64p, C.c_size_t, u64p, u64p, u64p]),
+    "plk_sigma_table": (C.c_int, [C.c_void_p, u64pp, C.c_size_t, u64pp]),
+    "plk_dev_sigma_table": (C.c_int, [C.c_void_p, C.c_void_p, u64pp, C.c_size_t, u64pp]),
     "plk_dev_ntt_batch": (C.c_int, [C.c_void_p, C.c_void_p, u64pp, u32p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, u64pp]),
     "plk_dev_ntt_strided": (C.c_int, [C.c_void_p, C.c_void_p, u64p, C.c_size_t, C.c_uint32, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, u64p, C.c_size_t]),
     "plk_dev_mul": (C.c_int, [C.c_void_p, C.c_void_p, u64p, u64p, C.c_size_t, u64p]),

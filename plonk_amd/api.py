@@ -19,6 +19,8 @@ from . import _lib
 
 #: `ASTKind` declaration order, src/ast.rs:56-66 — the index of a selector column in the C ABI
 AST_KINDS = ("Int", "Bool", "Add", "Sub", "Mult", "Div", "Eq", "Not", "If")
+#: marks a wire the row's operation does not use, in the node-id columns of build_permutation_table
+NO_WIRE = _lib.NO_WIRE
 
 
 class PlonkError(RuntimeError):
@@ -323,6 +325,20 @@ def build_permutation_constraint_evaluation_polynomial(polynomials: PermutationP
     b, g = _fe(beta), _fe(gamma)
     c.check(c.lib.plk_perm_constraints(c.handle, _p(z), _table(sig), _table(wires), nc, N, _p(b), _p(g), z_shift, _p(out)))
     return out
+
+
+def build_permutation_table(node_ids: Sequence[np.ndarray], ctx: Optional[Context] = None) -> PermutationTable:
+    """build_permutation_trace + build_permutation_table (src/permutation_polynomial.rs:18-39, :79-202) on
+    the flattened trace: `node_ids[w][j]` is the node id on wire w (inputs 0-2, output 3) of global row j,
+    `NO_WIRE` where the row's operation has no such wire.  Returns the row-valued sigma columns."""
+    c = _ctx(ctx)
+    cols = [_idx(a, "node_ids") for a in node_ids]
+    if len(cols) != 4 or any(a.shape[0] != cols[0].shape[0] for a in cols):
+        raise ValueError("node_ids: four columns of one length expected")
+    n = cols[0].shape[0]
+    out = [np.empty((n,), dtype=np.uint64) for _ in range(4)]
+    c.check(c.lib.plk_sigma_table(c.handle, _table(cols), n, _table(out)))
+    return PermutationTable(*out)
 
 
 def prove_round23(evaluation_table: GateEvaluationTable, permutation_table: PermutationTable, beta: np.ndarray,

@@ -16,6 +16,7 @@
 #include "field.cuh"
 #include "grand_product.cuh"
 #include "ntt.cuh"
+#include "sigma_table.cuh"
 
 using namespace plk;
 
@@ -524,6 +525,56 @@ int launch_round23(plk_ctx* ctx, hipStream_t s, const uint64_t* const wires[4], 
   return PLK_OK;
 }
 
+// sigma table of n rows from node ids (device pointers), enqueued on s
+int launch_sigma_table(plk_ctx* ctx, hipStream_t s, const uint64_t* const node_ids[4], size_t n, uint64_t* const sigma_out[4]) {
+  if (n == 0) return PLK_OK;
+  if (n > (size_t(1) << 30)) return fail(ctx, PLK_ERR_ARG, "sigma table: more than 2^30 rows");
+  SigCols cols;
+  for (int k = 0; k < 4; ++k) {
+    if (!node_ids[k] || !sigma_out[k]) return fail(ctx, PLK_ERR_ARG, "null column pointer");
+    cols.node[k] = node_ids[k];
+    cols.sigma[k] = sigma_out[k];
+  }
+  const uint64_t total = 4 * (uint64_t)n;
+  const uint32_t waves = (uint32_t)((total + SIG_CHUNK - 1) / SIG_CHUNK);
+  const uint64_t entries = (uint64_t)SIG_BINS * waves;
+  int rc;
+  void *pk, *pv, *ph;
+  if ((rc = ws_get(ctx, "sig_keys", 2 * total * 8, &pk))) return rc;
+  if ((rc = ws_get(ctx, "sig_vals", 2 * total * 4, &pv))) return rc;
+  if ((rc = ws_get(ctx, "sig_hist", entries * 4 + 8, &ph))) return rc;
+  uint64_t* keys[2] = {(uint64_t*)pk, (uint64_t*)pk + total};
+  uint32_t* vals[2] = {(uint32_t*)pv, (uint32_t*)pv + total};
+  uint64_t* or_bits = (uint64_t*)ph;             // 8-byte aligned head of the slot
+  uint32_t* hist = (uint32_t*)((char*)ph + 8);
+  HIP_TRY(ctx, hipMemsetAsync(or_bits, 0, 8, s));
+  const unsigned ew_blocks = (unsigned)((total + 255) / 256);
+  // sort: read 8 B per wire, then 8 passes of (8 + 4) B in and out; link: read 12 B twice, write 8 B
+  // algorithmic bytes: 4 node ids in and 4 row indices out per row, in equal shares over the 10 steps
+  const double alg = (32.0 * (double)n + 32.0 * (double)n) / 10.0;
+  {
+    ProfScope ps(ctx, s, "sig_keys_kernel", alg);
+    hipLaunchKernelGGL(sig_keys_kernel, dim3(ew_blocks), dim3(256), 0, s, cols, (uint64_t)n, keys[0], vals[0], or_bits);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  int cur = 0;
+  for (int pass = 0; pass < 8; ++pass) {
+    ProfScope ps(ctx, s, "sig_sort_pass", alg);
+    hipLaunchKernelGGL(sig_hist_kernel, dim3(waves), dim3(64), 0, s, (const uint64_t*)keys[cur], total, pass, (const uint64_t*)or_bits, hist, waves);
+    hipLaunchKernelGGL(sig_scan_kernel, dim3(1), dim3(SIG_SCAN_THREADS), 0, s, hist, entries, pass, (const uint64_t*)or_bits);
+    hipLaunchKernelGGL(sig_scatter_kernel, dim3(waves), dim3(64), 0, s, (const uint64_t*)keys[cur], (const uint32_t*)vals[cur], total, pass,
+                       (const uint64_t*)or_bits, (const uint32_t*)hist, waves, keys[cur ^ 1], vals[cur ^ 1]);
+    HIP_TRY(ctx, hipGetLastError());
+    cur ^= 1;
+  }
+  {
+    ProfScope ps(ctx, s, "sig_link_kernel", alg);
+    hipLaunchKernelGGL(sig_link_kernel, dim3(ew_blocks), dim3(256), 0, s, (const uint64_t*)keys[cur], (const uint32_t*)vals[cur], total, cols);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  return PLK_OK;
+}
+
 int fetch_status(plk_ctx* ctx, hipStream_t s) {
   HIP_TRY(ctx, hipMemcpyAsync(ctx->status_host, ctx->status_dev, sizeof(GpStatus), hipMemcpyDeviceToHost, s));
   HIP_TRY(ctx, hipStreamSynchronize(s));
@@ -721,6 +772,13 @@ int plk_dev_grand_product(plk_ctx* ctx, void* stream, const uint64_t* const wire
   if (rc) return rc;
   if (!wires || !sigma) return fail(ctx, PLK_ERR_ARG, "null pointer table");
   return launch_grand_product(ctx, (hipStream_t)stream, wires, sigma, n, beta, gamma, z_out);
+}
+
+int plk_dev_sigma_table(plk_ctx* ctx, void* stream, const uint64_t* const node_ids[4], size_t n, uint64_t* const sigma_out[4]) {
+  int rc = use_device(ctx);
+  if (rc) return rc;
+  if (!node_ids || !sigma_out) return fail(ctx, PLK_ERR_ARG, "null pointer table");
+  return launch_sigma_table(ctx, (hipStream_t)stream, node_ids, n, sigma_out);
 }
 
 int plk_dev_gate_constraint_eval(plk_ctx* ctx, void* stream, const uint64_t* const wire_evals[4],
@@ -952,6 +1010,24 @@ int plk_grand_product(plk_ctx* ctx, const uint64_t* const wires[4], const uint64
   if ((rc = launch_grand_product(ctx, ctx->stream, w, sg, n, beta, gamma, (uint64_t*)dz))) return rc;
   if ((rc = fetch_status(ctx, ctx->stream))) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(z_out, dz, (n + 1) * ELEM, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return PLK_OK;
+}
+
+int plk_sigma_table(plk_ctx* ctx, const uint64_t* const node_ids[4], size_t n, uint64_t* const sigma_out[4]) {
+  int rc = use_device(ctx);
+  if (rc) return rc;
+  if (!node_ids || !sigma_out) return fail(ctx, PLK_ERR_ARG, "null pointer");
+  if (n == 0) return PLK_OK;
+  Staged st(ctx);
+  const uint64_t* nd[4]; uint64_t* sg[4];
+  for (int k = 0; k < 4; ++k) {
+    if (!node_ids[k] || !sigma_out[k]) return fail(ctx, PLK_ERR_ARG, "null column pointer");
+    void *d, *e; if ((rc = st.upload(node_ids[k], n * 8, &d))) return rc; if ((rc = st.alloc(n * 8, &e))) return rc;
+    nd[k] = (const uint64_t*)d; sg[k] = (uint64_t*)e;
+  }
+  if ((rc = launch_sigma_table(ctx, ctx->stream, nd, n, sg))) return rc;
+  for (int k = 0; k < 4; ++k) HIP_TRY(ctx, hipMemcpyAsync(sigma_out[k], sg[k], n * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return PLK_OK;
 }

@@ -91,6 +91,13 @@ class DeviceProver:
                                                   1 if inverse else 0, _table(out)))
         return out
 
+    def sigma_table(self, node_ids: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+        """Permutation table from four `(n,) int64` node-id columns (-1 = unused wire)."""
+        n = node_ids[0].shape[0]
+        out = [torch.empty((n,), dtype=torch.int64, device=self.device) for _ in range(4)]
+        self.ctx.check(self.lib.plk_dev_sigma_table(self.ctx.handle, self._stream(), _table(node_ids), n, _table(out)))
+        return out
+
     def grand_product(self, dc: DeviceCircuit, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         z = self.empty(dc.n + 1) if out is None else out
         self.ctx.check(self.lib.plk_dev_grand_product(self.ctx.handle, self._stream(), _table(dc.wires), _table(dc.sigma), dc.n,

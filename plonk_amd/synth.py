@@ -119,6 +119,26 @@ def make_circuit(n: int, circuit_id: int = 0, kinds=AST_KINDS) -> Circuit:
 R_INV_INT = pow(1 << 256, -1, P_INT)
 
 
+def make_node_ids(n: int, circuit_id: int = 0, leaves: int = 0):
+    """Seeded flattened trace for the sigma-table step: four `(n,) uint64` node-id columns.
+
+    Row j is an operation of arity 1 + (r_j mod 3) whose output is a fresh node `leaves + j`; each
+    used input wire carries a uniformly chosen earlier node (a leaf or an earlier row's output), so
+    nodes are shared by a varying number of positions; unused wires hold NO_WIRE.  `leaves` defaults
+    to max(n // 4, 1).  Streams 16..19 of the circuit: arity, then one per input wire."""
+    from .api import NO_WIRE
+    leaves = leaves or max(n // 4, 1)
+    base = SEED_BASE + CIRCUIT_STRIDE * circuit_id
+    j = np.arange(n, dtype=np.uint64)
+    arity = splitmix64(base + 16, n) % np.uint64(3) + np.uint64(1)
+    cols = []
+    for w in range(3):
+        pick = splitmix64(base + 17 + w, n) % (np.uint64(leaves) + j)
+        cols.append(np.where(arity > np.uint64(w), pick, np.uint64(NO_WIRE)))
+    cols.append(np.uint64(leaves) + j)
+    return cols
+
+
 def ints_to_mont(values) -> np.ndarray:
     out = np.empty((len(values), 4), dtype=np.uint64)
     for i, v in enumerate(values):

@@ -1,0 +1,98 @@
+"""CPU checks of the sigma-table step: the reference-shaped restatement, the flattened restatement
+and the C restatement agree with each other and with the committed vectors."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+import c_oracle as co
+import plonk_oracle as po
+from plonk_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def sigma_vectors():
+    with open(os.path.join(ROOT, "tests", "golden", "sigma_vectors.json")) as f:
+        return json.load(f)
+
+
+def case_node_ids(case):
+    if "node_ids" in case:
+        return [[int(x) for x in c] for c in case["node_ids"]]
+    g = case["generator"]
+    return [[int(x) for x in c] for c in synth.make_node_ids(g["n"], g["circuit_id"])]
+
+
+def as_lists(t):
+    return [t.sigma1, t.sigma2, t.sigma3, t.sigma_output]
+
+
+def trace_of(case):
+    tr = case["trace"]
+    conv = lambda d: {k: [(tuple(i), o) for i, o in rows] for k, rows in d.items()}
+    return po.ExecutionTrace(conv(tr["single_input"]), conv(tr["double_input"]), conv(tr["triple_input"]))
+
+
+def test_vectors_reproduce(sigma_vectors):
+    assert sigma_vectors["no_wire"] == po.NO_WIRE == 2 ** 64 - 1
+    for case in sigma_vectors["cases"]:
+        ids = case_node_ids(case)
+        assert as_lists(po.sigma_table_from_node_ids(ids)) == case["sigma"], case["name"]
+        if len(ids[0]):
+            got = co.sigma_table([np.array(c, dtype=np.uint64) for c in ids])
+            assert [[int(x) for x in c] for c in got] == case["sigma"], case["name"]
+        if "trace" in case:
+            tr = trace_of(case)
+            assert po.flatten_trace(tr) == ids
+            t = po.build_permutation_table(tr, po.offset_table_build(tr), po.build_permutation_trace(tr))
+            assert as_lists(t) == case["sigma"], case["name"]
+
+
+def test_example_is_three_fixed_points(sigma_vectors):
+    """Add(Int 40, Int 2): three nodes, one position each -> every wire maps to its own row."""
+    case = sigma_vectors["cases"][0]
+    assert case["name"] == "example_add_40_2"
+    assert case["sigma"] == [[0], [0], [0], [0]]
+
+
+def test_flattening_matches_the_reference_shape_under_any_map_order():
+    """HashMap iteration order is not fixed in the reference; whatever order the kinds come in, the
+    flattened columns (rows in offset-table order) give the table the structured code builds."""
+    rng = random.Random(11)
+    for _ in range(100):
+        nn = rng.randint(1, 10)
+        rows = lambda ar, cnt: [(tuple(rng.randrange(nn) for _ in range(ar)), rng.randrange(nn)) for _ in range(cnt)]
+        k2 = list(po.DOUBLE_INPUT)
+        rng.shuffle(k2)
+        tr = po.ExecutionTrace({k: rows(1, rng.randint(0, 4)) for k in po.SINGLE_INPUT if rng.random() < 0.8},
+                               {k: rows(2, rng.randint(0, 4)) for k in k2 if rng.random() < 0.8},
+                               {k: rows(3, rng.randint(0, 4)) for k in po.TRIPLE_INPUT if rng.random() < 0.8})
+        t = po.build_permutation_table(tr, po.offset_table_build(tr), po.build_permutation_trace(tr))
+        assert as_lists(po.sigma_table_from_node_ids(po.flatten_trace(tr))) == as_lists(t)
+
+
+def test_cycle_structure():
+    """sigma restricted to a node's positions is one cycle through all of them (as rows), and every
+    column is a map into [0, n)."""
+    n = 4096
+    ids = synth.make_node_ids(n)
+    sig = co.sigma_table(ids)
+    for s in sig:
+        assert s.max() < n
+    # walking next-position links from any position returns to it after exactly group-size steps
+    flat = {}
+    for j in range(n):
+        for w in range(4):
+            if int(ids[w][j]) != po.NO_WIRE:
+                flat.setdefault(int(ids[w][j]), []).append((j, w))
+    rng = random.Random(3)
+    for node in rng.sample(sorted(flat), 50):
+        pos = flat[node]
+        rows_next = [int(sig[w][j]) for j, w in pos]
+        assert rows_next == [pos[(i + 1) % len(pos)][0] for i in range(len(pos))]
+    unused = [(j, w) for w in range(3) for j in range(n) if int(ids[w][j]) == po.NO_WIRE]
+    assert unused and all(int(sig[w][j]) == j for j, w in unused)
