@@ -542,34 +542,39 @@ int launch_sigma_table(plk_ctx* ctx, hipStream_t s, const uint64_t* const node_i
   void *pk, *pv, *ph;
   if ((rc = ws_get(ctx, "sig_keys", 2 * total * 8, &pk))) return rc;
   if ((rc = ws_get(ctx, "sig_vals", 2 * total * 4, &pv))) return rc;
-  if ((rc = ws_get(ctx, "sig_hist", entries * 4 + 8, &ph))) return rc;
-  uint64_t* keys[2] = {(uint64_t*)pk, (uint64_t*)pk + total};
-  uint32_t* vals[2] = {(uint32_t*)pv, (uint32_t*)pv + total};
+  const uint32_t scan_tiles = (uint32_t)((entries + SIG_SCAN_TILE - 1) / SIG_SCAN_TILE);
+  if ((rc = ws_get(ctx, "sig_hist", 8 + (entries + scan_tiles) * 4, &ph))) return rc;
+  SigPairs pairs;
+  pairs.keys[0] = (uint64_t*)pk; pairs.keys[1] = (uint64_t*)pk + total;
+  pairs.vals[0] = (uint32_t*)pv; pairs.vals[1] = (uint32_t*)pv + total;
   uint64_t* or_bits = (uint64_t*)ph;             // 8-byte aligned head of the slot
   uint32_t* hist = (uint32_t*)((char*)ph + 8);
+  uint32_t* sums = hist + entries;
   HIP_TRY(ctx, hipMemsetAsync(or_bits, 0, 8, s));
   const unsigned ew_blocks = (unsigned)((total + 255) / 256);
-  // sort: read 8 B per wire, then 8 passes of (8 + 4) B in and out; link: read 12 B twice, write 8 B
   // algorithmic bytes: 4 node ids in and 4 row indices out per row, in equal shares over the 10 steps
   const double alg = (32.0 * (double)n + 32.0 * (double)n) / 10.0;
   {
     ProfScope ps(ctx, s, "sig_keys_kernel", alg);
-    hipLaunchKernelGGL(sig_keys_kernel, dim3(ew_blocks), dim3(256), 0, s, cols, (uint64_t)n, keys[0], vals[0], or_bits);
+    hipLaunchKernelGGL(sig_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, cols, (uint64_t)n, pairs.keys[0], pairs.vals[0], or_bits);
     HIP_TRY(ctx, hipGetLastError());
   }
-  int cur = 0;
+  // eight digit passes are enqueued; a pass whose digit is zero in every node id returns at once
   for (int pass = 0; pass < 8; ++pass) {
-    ProfScope ps(ctx, s, "sig_sort_pass", alg);
-    hipLaunchKernelGGL(sig_hist_kernel, dim3(waves), dim3(64), 0, s, (const uint64_t*)keys[cur], total, pass, (const uint64_t*)or_bits, hist, waves);
-    hipLaunchKernelGGL(sig_scan_kernel, dim3(1), dim3(SIG_SCAN_THREADS), 0, s, hist, entries, pass, (const uint64_t*)or_bits);
-    hipLaunchKernelGGL(sig_scatter_kernel, dim3(waves), dim3(64), 0, s, (const uint64_t*)keys[cur], (const uint32_t*)vals[cur], total, pass,
-                       (const uint64_t*)or_bits, (const uint32_t*)hist, waves, keys[cur ^ 1], vals[cur ^ 1]);
+    const std::string ptag = "/p" + std::to_string(pass);
+    { ProfScope ps(ctx, s, "sig_hist_kernel" + ptag, alg / 3);
+      hipLaunchKernelGGL(sig_hist_kernel, dim3(waves), dim3(64), 0, s, pairs, total, pass, (const uint64_t*)or_bits, hist, waves); }
+    { ProfScope ps(ctx, s, "sig_scan_kernel" + ptag, alg / 3);
+      hipLaunchKernelGGL(sig_scan_tiles_kernel, dim3(scan_tiles), dim3(SIG_SCAN_THREADS), 0, s, hist, entries, sums, pass, (const uint64_t*)or_bits);
+      hipLaunchKernelGGL(sig_scan_sums_kernel, dim3(1), dim3(SIG_SCAN_THREADS), 0, s, sums, scan_tiles, pass, (const uint64_t*)or_bits); }
+    ProfScope ps(ctx, s, "sig_scatter_kernel" + ptag, alg / 3);
+    hipLaunchKernelGGL(sig_scatter_kernel, dim3(waves), dim3(64), 0, s, pairs, total, pass, (const uint64_t*)or_bits,
+                       (const uint32_t*)hist, (const uint32_t*)sums, waves);
     HIP_TRY(ctx, hipGetLastError());
-    cur ^= 1;
   }
   {
     ProfScope ps(ctx, s, "sig_link_kernel", alg);
-    hipLaunchKernelGGL(sig_link_kernel, dim3(ew_blocks), dim3(256), 0, s, (const uint64_t*)keys[cur], (const uint32_t*)vals[cur], total, cols);
+    hipLaunchKernelGGL(sig_link_kernel, dim3(ew_blocks), dim3(256), 0, s, pairs, (const uint64_t*)or_bits, total, cols);
     HIP_TRY(ctx, hipGetLastError());
   }
   return PLK_OK;

@@ -26,6 +26,8 @@ constexpr uint64_t SIG_NO_WIRE = ~0ull;
 constexpr int SIG_CHUNK = 2048;        // pairs per wave (one wave per workgroup)
 constexpr int SIG_BINS = 257;          // 256 digit values + one bin that keeps unused wires last
 constexpr int SIG_SCAN_THREADS = 1024;
+constexpr int SIG_SCAN_ITEMS = 4;
+constexpr int SIG_SCAN_TILE = SIG_SCAN_THREADS * SIG_SCAN_ITEMS;   // histogram entries per scan workgroup
 
 struct SigCols {
   const uint64_t* node[4];
@@ -42,25 +44,45 @@ __device__ __forceinline__ bool sig_pass_is_identity(const uint64_t* or_bits, in
   return p > 0 && ((*or_bits >> (8 * p)) & 0xffu) == 0;
 }
 
+// The pairs ping-pong between two buffers; only real passes move them, so the buffer holding the
+// pairs before pass `p` (p = 8: after the last pass) is the number of real passes before p, mod 2.
+__device__ __forceinline__ int sig_buffer_before(const uint64_t* or_bits, int p) {
+  int real = 0;
+  for (int q = 0; q < p; ++q) real += sig_pass_is_identity(or_bits, q) ? 0 : 1;
+  return real & 1;
+}
+
+struct SigPairs {
+  uint64_t* keys[2];
+  uint32_t* vals[2];
+};
+
 // pairs in position order: position = 4 * row + wire; also the OR of all used node ids
 __global__ __launch_bounds__(256) void sig_keys_kernel(SigCols cols, uint64_t n, uint64_t* keys, uint32_t* vals, uint64_t* or_bits) {
-  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;   // one row per thread
   uint64_t key = 0;
-  if (i < 4 * n) {
-    key = cols.node[i & 3][i >> 2];
-    keys[i] = key;
-    vals[i] = (uint32_t)i;
-    if (key == SIG_NO_WIRE) key = 0;
+  if (j < n) {
+    uint64_t k[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { k[w] = cols.node[w][j]; if (k[w] != SIG_NO_WIRE) key |= k[w]; }
+    uint4* kd = reinterpret_cast<uint4*>(keys + 4 * j);          // 32-byte aligned: 4 keys per row
+    kd[0] = make_uint4((uint32_t)k[0], (uint32_t)(k[0] >> 32), (uint32_t)k[1], (uint32_t)(k[1] >> 32));
+    kd[1] = make_uint4((uint32_t)k[2], (uint32_t)(k[2] >> 32), (uint32_t)k[3], (uint32_t)(k[3] >> 32));
+    const uint32_t p = (uint32_t)(4 * j);
+    *reinterpret_cast<uint4*>(vals + 4 * j) = make_uint4(p, p + 1, p + 2, p + 3);
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) key |= __shfl_xor(key, d);
-  if ((threadIdx.x & 63) == 0 && key) atomicOr((unsigned long long*)or_bits, (unsigned long long)key);
+  // one atomic per wave, and only while it still adds bits (nearly every wave finds them all set)
+  if ((threadIdx.x & 63) == 0 && (key & ~__atomic_load_n(or_bits, __ATOMIC_RELAXED)))
+    atomicOr((unsigned long long*)or_bits, (unsigned long long)key);
 }
 
 // per-wave digit counts: hist[bin * waves + wave]
-__global__ __launch_bounds__(64) void sig_hist_kernel(const uint64_t* keys, uint64_t total, int pass, const uint64_t* or_bits,
+__global__ __launch_bounds__(64) void sig_hist_kernel(SigPairs pairs, uint64_t total, int pass, const uint64_t* or_bits,
                                                       uint32_t* hist, uint32_t waves) {
   if (sig_pass_is_identity(or_bits, pass)) return;
+  const uint64_t* keys = pairs.keys[sig_buffer_before(or_bits, pass)];
   __shared__ uint32_t cnt[SIG_BINS];
   for (int b = threadIdx.x; b < SIG_BINS; b += 64) cnt[b] = 0;
   __syncthreads();
@@ -73,40 +95,74 @@ __global__ __launch_bounds__(64) void sig_hist_kernel(const uint64_t* keys, uint
   for (int b = threadIdx.x; b < SIG_BINS; b += 64) hist[(uint64_t)b * waves + blockIdx.x] = cnt[b];
 }
 
-// exclusive scan of the whole histogram in bin-major order (one workgroup)
-__global__ __launch_bounds__(SIG_SCAN_THREADS) void sig_scan_kernel(uint32_t* hist, uint64_t entries, int pass, const uint64_t* or_bits) {
-  if (sig_pass_is_identity(or_bits, pass)) return;
-  __shared__ uint32_t part[SIG_SCAN_THREADS];
-  const uint64_t per = (entries + SIG_SCAN_THREADS - 1) / SIG_SCAN_THREADS;
-  const uint64_t lo = min((uint64_t)threadIdx.x * per, entries), hi = min(lo + per, entries);
-  uint32_t sum = 0;
-  for (uint64_t e = lo; e < hi; ++e) sum += hist[e];
-  part[threadIdx.x] = sum;
-  __syncthreads();
-  for (int d = 1; d < SIG_SCAN_THREADS; d <<= 1) {   // Hillis-Steele inclusive scan
-    const uint32_t add = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
-    __syncthreads();
-    part[threadIdx.x] += add;
-    __syncthreads();
+// Exclusive scan of the whole histogram in bin-major order, in two steps: every workgroup scans
+// SIG_SCAN_TILE consecutive entries in place and leaves its total in sums[]; one workgroup then
+// turns sums[] into exclusive offsets.  The scatter kernel adds the two.
+__device__ __forceinline__ uint32_t sig_block_exclusive(uint32_t v, uint32_t* lds, uint32_t* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_up(inc, d);
+    if (lane >= d) inc += o;
   }
-  uint32_t run = part[threadIdx.x] - sum;
-  for (uint64_t e = lo; e < hi; ++e) { const uint32_t c = hist[e]; hist[e] = run; run += c; }
+  if (lane == 63) lds[wave] = inc;
+  __syncthreads();
+  uint32_t carry = 0, all = 0;
+  for (int w = 0; w < SIG_SCAN_THREADS / 64; ++w) {
+    const uint32_t t = lds[w];
+    if (w < wave) carry += t;
+    all += t;
+  }
+  __syncthreads();
+  *total = all;
+  return carry + inc - v;
 }
 
-// stable scatter of one wave's chunk; an identity pass copies instead
-__global__ __launch_bounds__(64) void sig_scatter_kernel(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t total, int pass,
-                                                         const uint64_t* or_bits, const uint32_t* hist, uint32_t waves,
-                                                         uint64_t* keys_out, uint32_t* vals_out) {
-  const uint64_t base = (uint64_t)blockIdx.x * SIG_CHUNK;
-  if (sig_pass_is_identity(or_bits, pass)) {
-    for (int it = 0; it < SIG_CHUNK / 64; ++it) {
-      const uint64_t i = base + it * 64 + threadIdx.x;
-      if (i < total) { keys_out[i] = keys_in[i]; vals_out[i] = vals_in[i]; }
-    }
-    return;
+__global__ __launch_bounds__(SIG_SCAN_THREADS) void sig_scan_tiles_kernel(uint32_t* hist, uint64_t entries, uint32_t* sums, int pass,
+                                                                          const uint64_t* or_bits) {
+  if (sig_pass_is_identity(or_bits, pass)) return;
+  __shared__ uint32_t lds[SIG_SCAN_THREADS / 64];
+  const uint64_t e0 = (uint64_t)blockIdx.x * SIG_SCAN_TILE + (uint64_t)threadIdx.x * SIG_SCAN_ITEMS;
+  uint32_t c[SIG_SCAN_ITEMS], sum = 0;
+#pragma unroll
+  for (int k = 0; k < SIG_SCAN_ITEMS; ++k) { c[k] = e0 + k < entries ? hist[e0 + k] : 0; sum += c[k]; }
+  uint32_t total;
+  uint32_t run = sig_block_exclusive(sum, lds, &total);
+#pragma unroll
+  for (int k = 0; k < SIG_SCAN_ITEMS; ++k) { if (e0 + k < entries) hist[e0 + k] = run; run += c[k]; }
+  if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(SIG_SCAN_THREADS) void sig_scan_sums_kernel(uint32_t* sums, uint32_t count, int pass, const uint64_t* or_bits) {
+  if (sig_pass_is_identity(or_bits, pass)) return;
+  __shared__ uint32_t lds[SIG_SCAN_THREADS / 64];
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < count; base += SIG_SCAN_THREADS) {   // uniform trip count
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = i < count ? sums[i] : 0;
+    uint32_t total;
+    const uint32_t ex = sig_block_exclusive(v, lds, &total);
+    if (i < count) sums[i] = carry + ex;
+    carry += total;
   }
+}
+
+// stable scatter of one wave's chunk into the other buffer; an identity pass moves nothing
+__global__ __launch_bounds__(64) void sig_scatter_kernel(SigPairs pairs, uint64_t total, int pass, const uint64_t* or_bits,
+                                                         const uint32_t* hist, const uint32_t* sums, uint32_t waves) {
+  if (sig_pass_is_identity(or_bits, pass)) return;
+  const int src = sig_buffer_before(or_bits, pass);
+  const uint64_t* keys_in = pairs.keys[src];
+  const uint32_t* vals_in = pairs.vals[src];
+  uint64_t* keys_out = pairs.keys[src ^ 1];
+  uint32_t* vals_out = pairs.vals[src ^ 1];
+  const uint64_t base = (uint64_t)blockIdx.x * SIG_CHUNK;
   __shared__ uint32_t off[SIG_BINS];
-  for (int b = threadIdx.x; b < SIG_BINS; b += 64) off[b] = hist[(uint64_t)b * waves + blockIdx.x];
+  for (int b = threadIdx.x; b < SIG_BINS; b += 64) {
+    const uint64_t e = (uint64_t)b * waves + blockIdx.x;
+    off[b] = hist[e] + sums[e / SIG_SCAN_TILE];
+  }
   __syncthreads();
   const uint64_t lane_lt = (1ull << threadIdx.x) - 1;
   for (int it = 0; it < SIG_CHUNK / 64; ++it) {
@@ -133,9 +189,12 @@ __global__ __launch_bounds__(64) void sig_scatter_kernel(const uint64_t* keys_in
 }
 
 // sigma of every position from the sorted pairs
-__global__ __launch_bounds__(256) void sig_link_kernel(const uint64_t* keys, const uint32_t* vals, uint64_t total, SigCols cols) {
+__global__ __launch_bounds__(256) void sig_link_kernel(SigPairs pairs, const uint64_t* or_bits, uint64_t total, SigCols cols) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
+  const int buf = sig_buffer_before(or_bits, 8);
+  const uint64_t* keys = pairs.keys[buf];
+  const uint32_t* vals = pairs.vals[buf];
   const uint64_t key = keys[i];
   const uint32_t pos = vals[i];
   uint32_t next;
