@@ -135,6 +135,23 @@ int plk_round23(plk_ctx* ctx, const uint64_t* const wires[PLK_NUM_WIRES], const 
 int plk_sigma_table(plk_ctx* ctx, const uint64_t* const node_ids[PLK_NUM_WIRES], size_t n,
                     uint64_t* const sigma_out[PLK_NUM_WIRES]);
 
+/* build_gate_evaluation_table — src/execution_trace.rs:248-302, completed: the reference handles
+ * the single-input tables only (:268-296, the rest "omitted", :298-299) and writes into vectors of
+ * length zero (:238-241), so it has no output to compare with; this follows the pattern it shows.
+ * The trace is flattened as for plk_sigma_table, plus
+ *   row_ops[j]  = PLK_ROW_OP(kind, inputs): the `ASTKind` index of row j's operation and its number
+ *                 of inputs (1, 2 or 3 = the table map it is filed in, src/execution_trace.rs:38-42);
+ *   node_values = the evaluated value of every node (NodeMeta::evaluated_value, src/ast.rs:6-9),
+ *                 n_values elements; this is the wire map: wire_map[(j, w)] = node_values[node_ids[w][j]],
+ *                 and a position whose id is PLK_NO_WIRE or >= n_values is absent from it.
+ * wires_out[w][j] = the mapped value if wire w is an input the operation has (w < inputs) or the
+ * output (w = 3) and the position is in the map, else default_val (:260-265, :287-288);
+ * sel_out[k][j] = one if kind == k else zero, for every k with sel_out[k] != NULL (:292-294). */
+#define PLK_ROW_OP(kind, inputs) ((uint8_t)((kind) | ((inputs) << 4)))
+int plk_gate_table_fill(plk_ctx* ctx, const uint8_t* row_ops, const uint64_t* const node_ids[PLK_NUM_WIRES], size_t n,
+                        const uint64_t* node_values, size_t n_values, const uint64_t default_val[4],
+                        uint64_t* const wires_out[PLK_NUM_WIRES], uint64_t* const sel_out[PLK_NUM_SELECTORS]);
+
 /* ---- device entry points (same arithmetic, device pointers, asynchronous) ---------------- */
 
 /* `batch` transforms of size N in one set of launches.  in[b] holds n_in valid elements
@@ -157,6 +174,11 @@ int plk_dev_mul(plk_ctx* ctx, void* stream, const uint64_t* a, const uint64_t* b
  * No counterpart in the reference (ark-poly runs one shared-memory FFT). */
 int plk_dev_twiddle_block(plk_ctx* ctx, void* stream, size_t N, int inverse, int scale_by_inverse_n, size_t rows, size_t cols,
                           size_t row0, size_t col0, uint64_t* out);
+
+/* plk_gate_table_fill on device memory (default_val stays a host pointer) */
+int plk_dev_gate_table_fill(plk_ctx* ctx, void* stream, const uint8_t* row_ops, const uint64_t* const node_ids[PLK_NUM_WIRES],
+                            size_t n, const uint64_t* node_values, size_t n_values, const uint64_t default_val[4],
+                            uint64_t* const wires_out[PLK_NUM_WIRES], uint64_t* const sel_out[PLK_NUM_SELECTORS]);
 
 /* plk_sigma_table on device columns (n uint64_t each) */
 int plk_dev_sigma_table(plk_ctx* ctx, void* stream, const uint64_t* const node_ids[PLK_NUM_WIRES], size_t n,

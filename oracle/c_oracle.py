@@ -171,3 +171,18 @@ def sigma_table(node_ids):
     if rc:
         raise OracleError(rc)
     return out
+
+
+def gate_table_fill(ops, node_ids, node_values, default_val, kinds_present=AST_KINDS):
+    """orc_gate_table_fill -> (4 wire columns, {kind: selector column})."""
+    ops = np.ascontiguousarray(ops, dtype=np.uint8)
+    cols = [_c(a) for a in node_ids]
+    vals = _c(node_values)
+    n = ops.shape[0]
+    w_out = [np.empty((n, 4), dtype=np.uint64) for _ in range(4)]
+    s_out = [np.empty((n, 4), dtype=np.uint64) if k in kinds_present else None for k in AST_KINDS]
+    rc = lib().orc_gate_table_fill(ops.ctypes.data_as(C.POINTER(C.c_uint8)), _tab(cols), C.c_size_t(n), _p(vals),
+                                   C.c_size_t(vals.shape[0]), _p(_c(default_val)), _tab(w_out), _tab(s_out))
+    if rc:
+        raise OracleError(rc)
+    return w_out, {k: s_out[i] for i, k in enumerate(AST_KINDS) if s_out[i] is not None}

@@ -358,6 +358,27 @@ int orc_sigma_table(const u64* const node_ids[4], size_t n, u64* const sigma_out
   return 0;
 }
 
+/* ---- gate evaluation table from the flattened trace ----
+ * build_gate_evaluation_table, src/execution_trace.rs:248-302, completed for all three table maps:
+ * row_ops[j] = ASTKind index | inputs << 4; wires_out[w][j] = node_values[node_ids[w][j]] when wire w
+ * is an input the operation has or the output and the id is below n_values, else default_val
+ * (:260-265, :286-289); sel_out[k][j] = one if kind == k else zero (:292-294). */
+int orc_gate_table_fill(const uint8_t* row_ops, const u64* const node_ids[4], size_t n, const u64* node_values, size_t n_values,
+                        const u64* default_val, u64* const wires_out[4], u64* const sel_out[9]) {
+  const fe one = fe_to_mont((fe){{1, 0, 0, 0}}), zero = {{0, 0, 0, 0}};
+  for (size_t j = 0; j < n; ++j) {
+    const unsigned kind = row_ops[j] & 15u, inputs = row_ops[j] >> 4;
+    for (int w = 0; w < 4; ++w) {
+      const u64 id = node_ids[w][j];
+      const int wired = (w == 3 || (unsigned)w < inputs) && id < n_values;
+      memcpy(wires_out[w] + 4 * j, wired ? node_values + 4 * id : default_val, 32);
+    }
+    for (unsigned k = 0; k < 9; ++k)
+      if (sel_out[k]) memcpy(sel_out[k] + 4 * j, kind == k ? &one : &zero, 32);
+  }
+  return 0;
+}
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -33,6 +33,7 @@ NO_WIRE = (1 << 64) - 1
 u64p = C.POINTER(C.c_uint64)
 u64pp = C.POINTER(u64p)
 u32p = C.POINTER(C.c_uint32)
+u8p = C.POINTER(C.c_uint8)
 BUILDER_FN = C.CFUNCTYPE(C.c_size_t, C.c_void_p, u64p, C.c_size_t)
 
 #: every symbol include/plonk_hip.h declares: name -> (restype, argtypes)
@@ -52,6 +53,8 @@ SIGNATURES = {
     "plk_perm_polys": (C.c_int, [C.c_void_p, u64pp, u64pp, C.c_size_t, C.c_size_t, u64p, u64p, u64pp, u64p, u64p]),
     "plk_perm_constraints": (C.c_int, [C.c_void_p, u64p, u64pp, u64pp, C.c_size_t, C.c_size_t, u64p, u64p, C.c_size_t, u64p]),
     "plk_round23": (C.c_int, [C.c_void_p, u64pp, u64pp, u64pp, C.c_size_t, C.c_size_t, u64p, u64p, C.c_size_t, u64p, u64p, u64p]),
+    "plk_gate_table_fill": (C.c_int, [C.c_void_p, u8p, u64pp, C.c_size_t, u64p, C.c_size_t, u64p, u64pp, u64pp]),
+    "plk_dev_gate_table_fill": (C.c_int, [C.c_void_p, C.c_void_p, u8p, u64pp, C.c_size_t, u64p, C.c_size_t, u64p, u64pp, u64pp]),
     "plk_sigma_table": (C.c_int, [C.c_void_p, u64pp, C.c_size_t, u64pp]),
     "plk_dev_sigma_table": (C.c_int, [C.c_void_p, C.c_void_p, u64pp, C.c_size_t, u64pp]),
     "plk_dev_ntt_batch": (C.c_int, [C.c_void_p, C.c_void_p, u64pp, u32p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, u64pp]),

@@ -327,6 +327,37 @@ def build_permutation_constraint_evaluation_polynomial(polynomials: PermutationP
     return out
 
 
+def row_ops(kinds: Sequence[str], inputs: Sequence[int]) -> np.ndarray:
+    """Row descriptors of the flattened trace: `ASTKind` index | number of inputs << 4, one byte per row."""
+    k = np.array([AST_KINDS.index(x) for x in kinds], dtype=np.uint8)
+    a = np.asarray(inputs, dtype=np.uint8)
+    if k.shape != a.shape or ((a < 1) | (a > 3)).any():
+        raise ValueError("row_ops: one kind and an input count of 1..3 per row")
+    return k | (a << np.uint8(4))
+
+
+def build_gate_evaluation_table(ops: np.ndarray, node_ids: Sequence[np.ndarray], node_values: np.ndarray, default_val: np.ndarray,
+                                kinds_present: Optional[Sequence[str]] = None, ctx: Optional[Context] = None) -> GateEvaluationTable:
+    """build_gate_evaluation_table (src/execution_trace.rs:248-302, completed) on the flattened trace:
+    `ops` from row_ops(), `node_ids` as for build_permutation_table, `node_values` the `(m, 4)` evaluated
+    value of every node.  Selector columns are produced for `kinds_present` (default: the kinds that occur)."""
+    c = _ctx(ctx)
+    ops = np.ascontiguousarray(ops, dtype=np.uint8)
+    cols = [_idx(a, "node_ids") for a in node_ids]
+    n = ops.shape[0]
+    if len(cols) != 4 or any(a.shape[0] != n for a in cols):
+        raise ValueError("node_ids: four columns of one length expected")
+    vals = _col(node_values, "node_values")
+    if kinds_present is None:
+        kinds_present = [AST_KINDS[k] for k in sorted(set((ops & np.uint8(15)).tolist()))]
+    w_out = [np.empty((n, 4), dtype=np.uint64) for _ in range(4)]
+    s_out = [np.empty((n, 4), dtype=np.uint64) if k in kinds_present else None for k in AST_KINDS]
+    dv = _fe(default_val)
+    c.check(c.lib.plk_gate_table_fill(c.handle, ops.ctypes.data_as(_lib.u8p), _table(cols), n, _p(vals), vals.shape[0], _p(dv),
+                                      _table(w_out), _table(s_out)))
+    return GateEvaluationTable(*w_out, selectors={k: s_out[i] for i, k in enumerate(AST_KINDS) if s_out[i] is not None})
+
+
 def build_permutation_table(node_ids: Sequence[np.ndarray], ctx: Optional[Context] = None) -> PermutationTable:
     """build_permutation_trace + build_permutation_table (src/permutation_polynomial.rs:18-39, :79-202) on
     the flattened trace: `node_ids[w][j]` is the node id on wire w (inputs 0-2, output 3) of global row j,

@@ -14,6 +14,7 @@
 
 #include "constraints.cuh"
 #include "field.cuh"
+#include "gate_table.cuh"
 #include "grand_product.cuh"
 #include "ntt.cuh"
 #include "sigma_table.cuh"
@@ -525,6 +526,30 @@ int launch_round23(plk_ctx* ctx, hipStream_t s, const uint64_t* const wires[4], 
   return PLK_OK;
 }
 
+// gate evaluation table of n rows (device pointers), enqueued on s
+int launch_gate_table_fill(plk_ctx* ctx, hipStream_t s, const uint8_t* row_ops, const uint64_t* const node_ids[4], size_t n,
+                           const uint64_t* node_values, size_t m, const uint64_t default_val[4], uint64_t* const wires_out[4],
+                           uint64_t* const sel_out[9]) {
+  if (n == 0) return PLK_OK;
+  if (!row_ops || !default_val || (m && !node_values)) return fail(ctx, PLK_ERR_ARG, "null pointer");
+  GateTableCols cols{};
+  int ncols = 4;
+  for (int k = 0; k < 4; ++k) {
+    if (!node_ids[k] || !wires_out[k]) return fail(ctx, PLK_ERR_ARG, "null column pointer");
+    cols.node[k] = node_ids[k];
+    cols.wire[k] = wires_out[k];
+  }
+  for (int k = 0; k < 9; ++k) { cols.sel[k] = sel_out ? sel_out[k] : nullptr; ncols += cols.sel[k] != nullptr; }
+  const Fe dv = fe_from_limbs64(default_val);
+  if (!fe_is_canonical(dv)) return fail(ctx, PLK_ERR_ARG, "default_val is not a reduced field element");
+  // per row: 1 op byte + 4 node ids + up to 4 gathered values in, the table's columns out
+  ProfScope ps(ctx, s, "gate_table_fill_kernel", (1.0 + 32.0 + 128.0 + 32.0 * ncols) * (double)n);
+  hipLaunchKernelGGL(gate_table_fill_kernel, dim3((unsigned)((n + GT_THREADS - 1) / GT_THREADS)), dim3(GT_THREADS), 0, s, cols, row_ops,
+                     (uint64_t)n, node_values, (uint64_t)m, dv, fe_one());
+  HIP_TRY(ctx, hipGetLastError());
+  return PLK_OK;
+}
+
 // sigma table of n rows from node ids (device pointers), enqueued on s
 int launch_sigma_table(plk_ctx* ctx, hipStream_t s, const uint64_t* const node_ids[4], size_t n, uint64_t* const sigma_out[4]) {
   if (n == 0) return PLK_OK;
@@ -779,6 +804,15 @@ int plk_dev_grand_product(plk_ctx* ctx, void* stream, const uint64_t* const wire
   return launch_grand_product(ctx, (hipStream_t)stream, wires, sigma, n, beta, gamma, z_out);
 }
 
+int plk_dev_gate_table_fill(plk_ctx* ctx, void* stream, const uint8_t* row_ops, const uint64_t* const node_ids[4], size_t n,
+                            const uint64_t* node_values, size_t n_values, const uint64_t default_val[4],
+                            uint64_t* const wires_out[4], uint64_t* const sel_out[9]) {
+  int rc = use_device(ctx);
+  if (rc) return rc;
+  if (!node_ids || !wires_out) return fail(ctx, PLK_ERR_ARG, "null pointer table");
+  return launch_gate_table_fill(ctx, (hipStream_t)stream, row_ops, node_ids, n, node_values, n_values, default_val, wires_out, sel_out);
+}
+
 int plk_dev_sigma_table(plk_ctx* ctx, void* stream, const uint64_t* const node_ids[4], size_t n, uint64_t* const sigma_out[4]) {
   int rc = use_device(ctx);
   if (rc) return rc;
@@ -1015,6 +1049,35 @@ int plk_grand_product(plk_ctx* ctx, const uint64_t* const wires[4], const uint64
   if ((rc = launch_grand_product(ctx, ctx->stream, w, sg, n, beta, gamma, (uint64_t*)dz))) return rc;
   if ((rc = fetch_status(ctx, ctx->stream))) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(z_out, dz, (n + 1) * ELEM, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return PLK_OK;
+}
+
+int plk_gate_table_fill(plk_ctx* ctx, const uint8_t* row_ops, const uint64_t* const node_ids[4], size_t n,
+                        const uint64_t* node_values, size_t n_values, const uint64_t default_val[4],
+                        uint64_t* const wires_out[4], uint64_t* const sel_out[9]) {
+  int rc = use_device(ctx);
+  if (rc) return rc;
+  if (!node_ids || !wires_out) return fail(ctx, PLK_ERR_ARG, "null pointer");
+  if (n == 0) return PLK_OK;
+  if (!row_ops) return fail(ctx, PLK_ERR_ARG, "null pointer");
+  Staged st(ctx);
+  const uint64_t* nd[4]; uint64_t* w[4]; uint64_t* sl[9];
+  void *ops, *vals;
+  if ((rc = st.upload(row_ops, n, &ops))) return rc;
+  if ((rc = st.upload(node_values, n_values * ELEM, &vals))) return rc;
+  for (int k = 0; k < 4; ++k) {
+    if (!node_ids[k] || !wires_out[k]) return fail(ctx, PLK_ERR_ARG, "null column pointer");
+    void *d, *e; if ((rc = st.upload(node_ids[k], n * 8, &d))) return rc; if ((rc = st.alloc(n * ELEM, &e))) return rc;
+    nd[k] = (const uint64_t*)d; w[k] = (uint64_t*)e;
+  }
+  for (int k = 0; k < 9; ++k) {
+    sl[k] = nullptr;
+    if (sel_out && sel_out[k]) { void* e; if ((rc = st.alloc(n * ELEM, &e))) return rc; sl[k] = (uint64_t*)e; }
+  }
+  if ((rc = launch_gate_table_fill(ctx, ctx->stream, (const uint8_t*)ops, nd, n, (const uint64_t*)vals, n_values, default_val, w, sl))) return rc;
+  for (int k = 0; k < 4; ++k) HIP_TRY(ctx, hipMemcpyAsync(wires_out[k], w[k], n * ELEM, hipMemcpyDeviceToHost, ctx->stream));
+  for (int k = 0; k < 9; ++k) if (sl[k]) HIP_TRY(ctx, hipMemcpyAsync(sel_out[k], sl[k], n * ELEM, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return PLK_OK;
 }

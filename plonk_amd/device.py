@@ -91,6 +91,19 @@ class DeviceProver:
                                                   1 if inverse else 0, _table(out)))
         return out
 
+    def gate_table_fill(self, ops: torch.Tensor, node_ids: Sequence[torch.Tensor], node_values: torch.Tensor, default_val,
+                        kinds_present: Sequence[str] = AST_KINDS):
+        """Gate evaluation table on device: `ops` `(n,) uint8`, node ids `(n,) int64`, `node_values` `(m, 4) int64`.
+        Returns (4 wire columns, {kind: selector column})."""
+        n = ops.shape[0]
+        wires = [self.empty(n) for _ in range(4)]
+        sels = {k: self.empty(n) for k in kinds_present}
+        dv = _host_fe(default_val)
+        self.ctx.check(self.lib.plk_dev_gate_table_fill(
+            self.ctx.handle, self._stream(), C.cast(C.c_void_p(ops.data_ptr()), _lib.u8p), _table(node_ids), n, _ptr(node_values),
+            node_values.shape[0], dv.ctypes.data_as(_lib.u64p), _table(wires), _table([sels.get(k) for k in AST_KINDS])))
+        return wires, sels
+
     def sigma_table(self, node_ids: Sequence[torch.Tensor]) -> List[torch.Tensor]:
         """Permutation table from four `(n,) int64` node-id columns (-1 = unused wire)."""
         n = node_ids[0].shape[0]

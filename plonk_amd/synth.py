@@ -139,6 +139,27 @@ def make_node_ids(n: int, circuit_id: int = 0, leaves: int = 0):
     return cols
 
 
+@dataclass
+class FlatTrace:
+    """A flattened execution trace: what the table-building steps before the hot path consume."""
+    ops: np.ndarray          # (n,) uint8: ASTKind index | inputs << 4
+    node_ids: list           # four (n,) uint64 columns, NO_WIRE on unused wires
+    node_values: np.ndarray  # (m, 4) uint64 Montgomery limbs, one evaluated value per node
+
+
+def make_trace(n: int, circuit_id: int = 0, leaves: int = 0) -> FlatTrace:
+    """make_node_ids plus operation kinds consistent with each row's input count (1: Not, 2: one of
+    Add/Sub/Mult/Div/Eq from stream 20, 3: If) and one random value per node (stream 21).  The values
+    are NOT required to satisfy the gates (as in make_circuit)."""
+    leaves = leaves or max(n // 4, 1)
+    base = SEED_BASE + CIRCUIT_STRIDE * circuit_id
+    ids = make_node_ids(n, circuit_id, leaves)
+    inputs = (splitmix64(base + 16, n) % np.uint64(3) + np.uint64(1)).astype(np.uint8)
+    two = (splitmix64(base + 20, n) % np.uint64(5) + np.uint64(2)).astype(np.uint8)
+    kind = np.where(inputs == 1, np.uint8(7), np.where(inputs == 2, two, np.uint8(8))).astype(np.uint8)
+    return FlatTrace(kind | (inputs << np.uint8(4)), ids, random_elements(base + 21, leaves + n))
+
+
 def ints_to_mont(values) -> np.ndarray:
     out = np.empty((len(values), 4), dtype=np.uint64)
     for i, v in enumerate(values):

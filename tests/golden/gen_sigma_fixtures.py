@@ -34,6 +34,16 @@ def structured_case(name, trace):
     }
 
 
+def gate_table_case(name, trace, node_values, default_val):
+    """build_gate_evaluation_table (completed pattern) on a structured trace + its flattened inputs."""
+    offsets = po.offset_table_build(trace)
+    t = po.build_gate_evaluation_table(trace, offsets, po.wire_map_from_node_values(trace, node_values), default_val)
+    hx = lambda v: [hex(x) for x in v]
+    return {"name": name, "ops": po.flatten_ops(trace), "node_ids": po.flatten_trace(trace), "node_values": hx(node_values),
+            "default_val": hex(default_val), "wires": [hx(c) for c in (t.input1, t.input2, t.input3, t.output)],
+            "selectors": {k: v for k, v in t.selectors.items()}}
+
+
 def flat_case(name, node_ids, generator=None):
     t = po.sigma_table_from_node_ids(node_ids)
     case = {"name": name, "sigma": [t.sigma1, t.sigma2, t.sigma3, t.sigma_output]}
@@ -70,9 +80,16 @@ def main():
     for n in (8, 16, 1000):
         cols = [[int(x) for x in c] for c in synth.make_node_ids(n)]
         cases.append(flat_case(f"synth_n{n}", cols, generator={"name": "plonk_amd.synth.make_node_ids", "n": n, "circuit_id": 0}))
+    gate_cases = []
+    # Add(Int 40, Int 2) with its evaluated values 40, 2 -> 42 (src/ast.rs:473-477)
+    gate_cases.append(gate_table_case("example_add_40_2", po.ExecutionTrace(double_input={"Add": [((1, 2), 0)]}), [42, 40, 2], 0))
+    shared = po.ExecutionTrace(single_input={"Not": [((11,), 12)]}, double_input={"Add": [((1, 2), 10)], "Mult": [((10, 10), 11)]},
+                               triple_input={"If": [((12, 10, 11), 13)]})
+    gate_cases.append(gate_table_case("shared_nodes", shared, [rng.randrange(po.P) for _ in range(14)], 7))
+    gate_cases.append(gate_table_case("nodes_without_value", shared, [rng.randrange(po.P) for _ in range(12)], po.P - 1))
     path = os.path.join(HERE, "sigma_vectors.json")
     with open(path, "w") as f:
-        json.dump({"no_wire": po.NO_WIRE, "cases": cases}, f)
+        json.dump({"no_wire": po.NO_WIRE, "cases": cases, "gate_table_cases": gate_cases}, f)
     print("wrote", path, os.path.getsize(path), "bytes")
 
 

@@ -96,3 +96,47 @@ def test_cycle_structure():
         assert rows_next == [pos[(i + 1) % len(pos)][0] for i in range(len(pos))]
     unused = [(j, w) for w in range(3) for j in range(n) if int(ids[w][j]) == po.NO_WIRE]
     assert unused and all(int(sig[w][j]) == j for j, w in unused)
+
+
+# ---- gate evaluation table (the completed build_gate_evaluation_table pattern)
+
+
+def test_gate_table_vectors_reproduce(sigma_vectors):
+    for case in sigma_vectors["gate_table_cases"]:
+        vals = [int(x, 16) for x in case["node_values"]]
+        dv = int(case["default_val"], 16)
+        kinds = list(case["selectors"])
+        t = po.gate_table_from_flat(case["ops"], case["node_ids"], vals, dv, kinds)
+        want = [[int(x, 16) for x in c] for c in case["wires"]]
+        assert [t.input1, t.input2, t.input3, t.output] == want, case["name"]
+        assert t.selectors == case["selectors"], case["name"]
+        w, sels = co.gate_table_fill(np.array(case["ops"], dtype=np.uint8), [np.array(c, dtype=np.uint64) for c in case["node_ids"]],
+                                     synth.ints_to_mont(vals), synth.ints_to_mont([dv])[0], kinds)
+        assert [synth.mont_to_ints(c) for c in w] == want, case["name"]
+        assert {k: synth.mont_to_ints(v) for k, v in sels.items()} == case["selectors"], case["name"]
+
+
+def test_example_gate_table(sigma_vectors):
+    """Add(Int 40, Int 2): one row a = 40, b = 2, unused third input = default, output 42, Add selected."""
+    case = sigma_vectors["gate_table_cases"][0]
+    assert [int(c[0], 16) for c in case["wires"]] == [40, 2, 0, 42]
+    assert case["selectors"] == {"Add": [1]}
+    # ... and that row satisfies the Add gate of src/execution_trace.rs:400
+    assert po.gate_expression("Add", 40, 2, 0, 42) == 0
+
+
+def test_gate_table_flattening_matches_the_reference_shape():
+    rng = random.Random(23)
+    for _ in range(100):
+        nn = rng.randint(1, 10)
+        rows = lambda ar, cnt: [(tuple(rng.randrange(nn) for _ in range(ar)), rng.randrange(nn)) for _ in range(cnt)]
+        k2 = list(po.DOUBLE_INPUT)
+        rng.shuffle(k2)
+        tr = po.ExecutionTrace({k: rows(1, rng.randint(0, 4)) for k in po.SINGLE_INPUT if rng.random() < 0.8},
+                               {k: rows(2, rng.randint(0, 4)) for k in k2 if rng.random() < 0.8},
+                               {k: rows(3, rng.randint(0, 4)) for k in po.TRIPLE_INPUT if rng.random() < 0.8})
+        nv = [rng.randrange(po.P) for _ in range(rng.randint(max(nn - 3, 0), nn))]
+        ref = po.build_gate_evaluation_table(tr, po.offset_table_build(tr), po.wire_map_from_node_values(tr, nv), 99)
+        kinds = [k for t in (tr.single_input, tr.double_input, tr.triple_input) for k in t]
+        got = po.gate_table_from_flat(po.flatten_ops(tr), po.flatten_trace(tr), nv, 99, kinds)
+        assert (ref.input1, ref.input2, ref.input3, ref.output, ref.selectors) == (got.input1, got.input2, got.input3, got.output, got.selectors)
