@@ -37,7 +37,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log-n", type=int, default=20, help="log2 of the number of rows")
     ap.add_argument("--blowup", type=int, default=4, help="evaluation domain = blowup * n")
-    ap.add_argument("--workload", default="round23", choices=["round23", "ntt", "round23-sharded", "batch", "sigma"],
+    ap.add_argument("--workload", default="round23", choices=["round23", "ntt", "round23-sharded", "batch", "tables"],
                     help="round23: the headline metric (default). ntt: ONE four-step transform of 2^log-n points sharded over "
                          "the GPUs (config 4 with --log-n 24). round23-sharded: ONE proof over all GPUs. "
                          "batch: --circuits independent circuits dealt round-robin (config 5 with --log-n 18 --circuits 64)")
@@ -128,31 +128,50 @@ def other_workloads(args, prover, dist, rank, world):
                     config={"workload": f"one transform of N=2^{args.log_n} sharded contiguously over {world} GPU(s), three "
                                         f"all-to-all exchanges of {(world - 1) * N // (world * world) * 32 / 2**20:.1f} MiB per GPU each"},
                     frac_of_hbm_roofline=round(gelem / NTT_ROOFLINE_GELEM, 4))
-    elif args.workload == "sigma":
-        ids = synth.make_node_ids(n, circuit_id=rank)
-        dev = [to_device(c, prover.device) for c in ids]
-        prover.sigma_table(dev)
+    elif args.workload == "tables":
+        # the two table-building steps before the path, from one flattened trace per GPU
+        import torch
+        tr = synth.make_trace(n, circuit_id=rank)
+        ids = [to_device(c, prover.device) for c in tr.node_ids]
+        ops = torch.from_numpy(tr.ops).to(prover.device)
+        vals = to_device(tr.node_values, prover.device)
+        dv = synth.ints_to_mont([0])[0]
+
+        def step():
+            prover.gate_table_fill(ops, ids, vals, dv)
+            prover.sigma_table(ids)
+        step()
+        torch.cuda.synchronize()
         prover.profile_begin()
-        dt = timed(lambda: prover.sigma_table(dev), args.steps, args.warmup, dist, prover.device)
+        dt = timed(step, args.steps, 0, dist, prover.device)
         prof = prover.profile_end()
         ms = dt * 1e3 / args.steps
-        alg = 64.0 * n                      # four node ids in, four row indices out per row
-        line = dict(base, metric=f"sigma table of n=2^{args.log_n} rows", value=round(ms, 4), unit="ms", ms_per_step=round(ms, 4),
-                    higher_is_better=False, scaling="weak", dtype="u64",
-                    config={"workload": f"permutation table from 4 node-id columns of 2^{args.log_n} rows per GPU (stable radix "
-                                        f"sort of 2^{args.log_n + 2} (node id, position) pairs + cycle links)"},
-                    roofline={"bound": "hbm", "achieved": round(alg / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
-                              "note": "whole step (10 launch groups); 64 algorithmic bytes per row"},
-                    kernels=[{"label": r["label"], "launches": r["launches"],
-                              "ms_per_step": round(r["total_ms"] / (args.steps + args.warmup), 4)} for r in prof])
+        fill = [r for r in prof if r["label"] == "gate_table_fill_kernel"][0]
+        fill_ms = fill["total_ms"] / fill["launches"]
+        fill_gbs = fill["alg_bytes"] / fill["launches"] / (fill_ms * 1e-3) / 1e9
+        sig_ms = sum(r["total_ms"] for r in prof if r["label"].startswith("sig_")) / args.steps
+        line = dict(base, metric=f"gate table + sigma table of n=2^{args.log_n} rows", value=round(ms, 4), unit="ms",
+                    ms_per_step=round(ms, 4), higher_is_better=False, scaling="weak", dtype="u64", warmup=1,
+                    config={"workload": f"flattened trace of 2^{args.log_n} rows per GPU -> 4 wire + 9 selector columns (gather by "
+                                        f"node id) and 4 sigma columns (stable radix sort of 2^{args.log_n + 2} (node id, position) "
+                                        f"pairs + cycle links)"},
+                    roofline={"bound": "hbm", "kernel": "gate_table_fill_kernel", "achieved": round(fill_gbs, 1), "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": round(fill_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                              "avg_launch_ms": round(fill_ms, 4),
+                              "note": "577 algorithmic bytes per row (1 + 32 + 128 in, 13 x 32 out)"},
+                    sigma_table={"ms": round(sig_ms, 4), "alg_GBps": round(64.0 * n / (sig_ms * 1e-3) / 1e9, 1),
+                                 "note": "64 algorithmic bytes per row; a radix sort moves 24 bytes per pair and real pass on top"},
+                    kernels=[{"label": r["label"], "launches": r["launches"], "ms_per_step": round(r["total_ms"] / args.steps, 4)}
+                             for r in prof])
         if world == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import c_oracle as co
             t0 = time.perf_counter()
-            co.sigma_table(ids)
+            co.gate_table_fill(tr.ops, tr.node_ids, tr.node_values, dv)
+            co.sigma_table(tr.node_ids)
             line["cpu_baseline"] = {"value": round((time.perf_counter() - t0) * 1e3, 2), "unit": "ms", "cores": 1, "kind": "port",
-                                    "sample": f"the same 2^{args.log_n} rows, sort-based C restatement (the reference uses HashMaps)"}
+                                    "sample": f"the same 2^{args.log_n} rows: C restatement, sort-based grouping (the reference "
+                                              f"groups with HashMaps)"}
     elif args.workload == "round23-sharded":
         N = args.blowup * n
         c = synth.make_circuit(n, circuit_id=0)
