@@ -214,14 +214,25 @@ def main():
     from plonk_amd import synth
     from plonk_amd.device import DeviceProver
 
+    if os.environ.get("PLONK_BENCH_WATCHDOG"):   # seconds; dumps every thread's stack and exits if the run is still going
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["PLONK_BENCH_WATCHDOG"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # Rehearsal on a box with fewer GPUs than ranks: PLONK_BENCH_SHARE_GPU=1 maps ranks onto the GPUs
+    # present and PLONK_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device).
+    if os.environ.get("PLONK_BENCH_SHARE_GPU") == "1":
+        local_rank %= max(torch.cuda.device_count(), 1)
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("PLONK_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     n, N = 1 << args.log_n, args.blowup << args.log_n
 
     prover = DeviceProver(local_rank)

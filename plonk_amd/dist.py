@@ -36,7 +36,15 @@ def _all_to_all(send: torch.Tensor, group=None) -> torch.Tensor:
     if world == 1:
         return send
     recv = torch.empty_like(send)
+    # RCCL orders the exchange on the current stream.  Any other backend given GPU tensors (gloo, used
+    # to rehearse several ranks on one GPU) stages through host memory on a helper thread; with
+    # launches still in flight around it that was seen to hang, so the device is drained on both sides.
+    staged = send.is_cuda and dist.get_backend(group) != "nccl"
+    if staged:
+        torch.cuda.synchronize()
     dist.all_to_all_single(recv, send.contiguous(), group=group)
+    if staged:
+        torch.cuda.synchronize()
     return recv
 
 

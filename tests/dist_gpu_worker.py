@@ -1,0 +1,56 @@
+"""Worker of tests/test_gpu_dist.py::test_two_ranks_share_the_gpu: two (or more) ranks on GPU 0,
+exchanges over gloo (RCCL refuses several ranks on one device), every local computation in
+libplonk_hip.so.  Checks plonk_amd.dist against the CPU oracle.  Exit code != 0 on any mismatch."""
+import faulthandler
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+import c_oracle as co
+from plonk_amd import dist as pdist
+from plonk_amd import synth
+from plonk_amd.device import DeviceProver, to_device, to_host
+
+
+def main():
+    faulthandler.dump_traceback_later(150, exit=True)
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    eng = DeviceProver(0)
+    d = eng.device
+
+    for log_n in (10, 17):
+        N = 1 << log_n
+        x = synth.random_elements(777 + log_n, N)
+        lo, hi = rank * N // world, (rank + 1) * N // world
+        for inverse in (False, True):
+            want = co.intt(x, N) if inverse else co.ntt(x, N)
+            got = pdist.four_step_ntt(to_device(x[lo:hi], d), N, eng, inverse=inverse)
+            assert np.array_equal(to_host(got), want[lo:hi]), (log_n, inverse)
+
+    n, N = 1 << 10, 1 << 12
+    c = synth.make_circuit(n, circuit_id=3)
+    dc = eng.upload(c)
+    sels = [dc.selectors.get(k) for k in co.AST_KINDS]
+    zr, gr, pr = co.round23(c.table.wires(), c.table.selectors, c.perm.columns(), N, c.beta, c.gamma)
+    lo, hi = rank * N // world, (rank + 1) * N // world
+    for _ in range(3):                           # repeated calls: workspace and exchange reuse
+        z, gate, perm = pdist.round23_poly_sharded(eng, dc.wires, sels, dc.sigma, c.beta, c.gamma, n, N)
+        eng.status()
+        assert np.array_equal(to_host(z), zr)
+        assert np.array_equal(to_host(gate), gr[lo:hi]), "gate chunk"
+        assert np.array_equal(to_host(perm), pr[lo:hi]), "perm chunk"
+
+    dist.barrier()
+    dist.destroy_process_group()
+    print(f"rank {rank}/{world} ok")
+
+
+if __name__ == "__main__":
+    main()

@@ -63,3 +63,18 @@ def test_poly_sharded_round23_single_rank(prover):
     prover.status()
     zr, gr, er = co.round23(c.table.wires(), c.table.selectors, c.perm.columns(), N, c.beta, c.gamma)
     assert np.array_equal(to_host(z), zr) and np.array_equal(to_host(g), gr) and np.array_equal(to_host(e), er)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_share_the_gpu(world):
+    """several ranks on GPU 0 (exchanges over gloo): the sharded transform and the one-proof-over-G-ranks
+    path with the HIP engine, against the CPU oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29620 + world), os.path.join(root, "tests", "dist_gpu_worker.py")]
+    r = subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS="2"), capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count(" ok") == world
