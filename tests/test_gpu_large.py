@@ -107,3 +107,44 @@ def test_device_constraint_kernels_match_host_entry_points(prover):
     prover.status()
     zr, gr, er = co.round23(c.table.wires(), c.table.selectors, c.perm.columns(), N, c.beta, c.gamma)
     assert np.array_equal(to_host(g), gr) and np.array_equal(to_host(e), er) and np.array_equal(to_host(z), zr)
+
+
+@pytest.mark.parametrize("log_n", [22, 26])
+def test_big_transforms_closed_form(prover, log_n):
+    """Sizes past the oracle's reach (2^26 also takes the two-level twiddle path of the first pass):
+    a sparse input has the closed-form transform X[k] = sum_i c_i w^(j_i k); random data round-trips."""
+    N = 1 << log_n
+    w = po.root_of_unity(N)
+    idx = [0, 1, 12345, N // 2 + 3, N - 1]
+    coef = [3, po.P - 1, 0x1234567890ABCDEF, 7, 2**200 + 9]
+    x = torch.zeros((N, 4), dtype=torch.int64, device=prover.device)
+    x[idx] = to_device(synth.ints_to_mont(coef), prover.device)
+    X = prover.ntt_batch([x], N)[0]
+    rng = np.random.default_rng(log_n)
+    ks = [0, 1, N - 1, N // 2] + [int(k) for k in rng.integers(0, N, size=24)]
+    got = synth.mont_to_ints(to_host(X[ks]))
+    for k, g in zip(ks, got):
+        assert g == sum(c * pow(w, j * k, po.P) for c, j in zip(coef, idx)) % po.P, k
+    back = prover.ntt_batch([X], N, inverse=True)[0]
+    assert torch.equal(back, x)
+    del X, back
+    # random residues below p (top limb below the modulus' top limb)
+    y = torch.randint(-2**63, 2**63 - 1, (N, 4), dtype=torch.int64, device=prover.device)
+    y[:, 3] = torch.randint(0, 0x7000000000000000, (N,), dtype=torch.int64, device=prover.device)
+    Y = prover.ntt_batch([y], N, inverse=True)[0]
+    assert torch.equal(prover.ntt_batch([Y], N)[0], y)
+    # linearity ties the random vector to the closed form: NTT(iNTT(y) + x) = y + NTT(x) at the sampled points
+    s = prover.ntt_batch([field_add(prover, Y, x)], N)[0]
+    want = [(a + b) % po.P for a, b in zip(synth.mont_to_ints(to_host(y[ks])), got)]
+    assert synth.mont_to_ints(to_host(s[ks])) == want
+
+
+def field_add(prover, a, b):
+    """a + b for a sparse b: the sum is formed on the host for the few non-zero rows of b."""
+    out = a.clone()
+    nz = torch.nonzero(b.any(dim=1)).flatten()
+    if nz.numel():
+        av = synth.mont_to_ints(to_host(a[nz]))
+        bv = synth.mont_to_ints(to_host(b[nz]))
+        out[nz] = to_device(synth.ints_to_mont([(p + q) % po.P for p, q in zip(av, bv)]), prover.device)
+    return out
