@@ -188,6 +188,21 @@ int plk_dev_grand_product(plk_ctx* ctx, void* stream, const uint64_t* const wire
                           const uint64_t* const sigma[PLK_NUM_WIRES], size_t n,
                           const uint64_t beta[4], const uint64_t gamma[4], uint64_t* z_out);
 
+/* The same grand product with the rows split over several GPUs (no counterpart in the reference, which
+ * runs one serial loop, src/permutation_polynomial.rs:227-259).  Every GPU holds the whole columns
+ * (the numerator gathers reach any row) and owns the rows [first, first + rows):
+ *   plk_dev_grand_product_local  - per-row terms and local scans, kept in the context; writes the
+ *       range's numerator product and denominator product to totals_out[0], totals_out[1] (2 elements);
+ *   (the caller gathers every range's totals, in row order, into totals_all: 2 * ranges elements)
+ *   plk_dev_grand_product_finish - applies the other ranges' products and the one inversion, and writes
+ *       z_after_out[i] = z[first + i + 1], i < rows (z[0] = 1 is not written).
+ * The two calls must follow each other on one context and stream with the same `rows`. */
+int plk_dev_grand_product_local(plk_ctx* ctx, void* stream, const uint64_t* const wires[PLK_NUM_WIRES],
+                                const uint64_t* const sigma[PLK_NUM_WIRES], size_t n, size_t first, size_t rows,
+                                const uint64_t beta[4], const uint64_t gamma[4], uint64_t* totals_out);
+int plk_dev_grand_product_finish(plk_ctx* ctx, void* stream, size_t rows, const uint64_t* totals_all, size_t ranges,
+                                 size_t mine, uint64_t* z_after_out);
+
 /* loop of src/execution_trace.rs:379-428 on columns already evaluated on the N-point domain */
 int plk_dev_gate_constraint_eval(plk_ctx* ctx, void* stream, const uint64_t* const wire_evals[PLK_NUM_WIRES],
                                  const uint64_t* const sel_evals[PLK_NUM_SELECTORS], size_t N, uint64_t* out);

@@ -62,6 +62,8 @@ SIGNATURES = {
     "plk_dev_mul": (C.c_int, [C.c_void_p, C.c_void_p, u64p, u64p, C.c_size_t, u64p]),
     "plk_dev_twiddle_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, u64p]),
     "plk_dev_grand_product": (C.c_int, [C.c_void_p, C.c_void_p, u64pp, u64pp, C.c_size_t, u64p, u64p, u64p]),
+    "plk_dev_grand_product_local": (C.c_int, [C.c_void_p, C.c_void_p, u64pp, u64pp, C.c_size_t, C.c_size_t, C.c_size_t, u64p, u64p, u64p]),
+    "plk_dev_grand_product_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, u64p, C.c_size_t, C.c_size_t, u64p]),
     "plk_dev_gate_constraint_eval": (C.c_int, [C.c_void_p, C.c_void_p, u64pp, u64pp, C.c_size_t, u64p]),
     "plk_dev_perm_constraint_eval": (C.c_int, [C.c_void_p, C.c_void_p, u64p, u64pp, u64pp, C.c_size_t, u64p, u64p, C.c_size_t, u64p]),
     "plk_dev_perm_constraint_eval_range": (C.c_int, [C.c_void_p, C.c_void_p, u64p, u64pp, u64pp, C.c_size_t, C.c_size_t, u64p, u64p, C.c_size_t, u64p]),

@@ -47,6 +47,7 @@ struct plk_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::map<std::pair<int, int>, NttPlan> plans;  // (log_n, inverse)
   std::map<std::string, DevBuf> ws;              // grow-only workspace slots
+  size_t gp_rows = 0;                            // rows of the grand-product range held in the workspace
   GpStatus* status_dev = nullptr;
   GpStatus* status_host = nullptr;  // pinned
   std::string last_error;
@@ -342,49 +343,81 @@ int status_reset(plk_ctx* ctx, hipStream_t s) {
   return PLK_OK;
 }
 
-int launch_grand_product(plk_ctx* ctx, hipStream_t s, const uint64_t* const wires[4], const uint64_t* const sigma[4],
-                         size_t n, const uint64_t beta_[4], const uint64_t gamma_[4], uint64_t* z_out) {
-  if (!z_out || !beta_ || !gamma_) return fail(ctx, PLK_ERR_ARG, "null pointer");
+// Grand product of the rows [first, first + rows) of an n-row circuit, first half: per-row terms,
+// block products and their scans, left in the context's workspace.  totals == nullptr: the range is
+// the whole circuit and the inversion is done here; otherwise the range's numerator and denominator
+// products are written to totals[0..1] (device) and gp_apply_carries must run before gp_finish.
+int gp_local(plk_ctx* ctx, hipStream_t s, const uint64_t* const wires[4], const uint64_t* const sigma[4], size_t n, size_t first,
+             size_t rows, const uint64_t beta_[4], const uint64_t gamma_[4], uint64_t* totals) {
+  if (!beta_ || !gamma_) return fail(ctx, PLK_ERR_ARG, "null pointer");
+  if (rows == 0 || first > n || rows > n - first) return fail(ctx, PLK_ERR_ARG, "row range outside the circuit");
   const Fe beta = fe_from_limbs64(beta_), gamma = fe_from_limbs64(gamma_);
   if (!fe_is_canonical(beta) || !fe_is_canonical(gamma)) return fail(ctx, PLK_ERR_ARG, "beta/gamma not reduced mod p");
-  const Fe one = fe_one();
-  if (n == 0) {  // z = [1]
-    HIP_TRY(ctx, hipMemcpyAsync(z_out, &one, ELEM, hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));
-    return PLK_OK;
-  }
   GpCols cols{};
   for (int k = 0; k < 4; ++k) {
     if (!wires[k] || !sigma[k]) return fail(ctx, PLK_ERR_ARG, "null column pointer");
     cols.v[k] = wires[k];
     cols.sigma[k] = sigma[k];
   }
-  const size_t nb = (n + GP_BLOCK_ROWS - 1) / GP_BLOCK_ROWS;
+  const size_t nb = (rows + GP_BLOCK_ROWS - 1) / GP_BLOCK_ROWS;
   void *num, *den, *bn, *bd;
   int rc;
-  if ((rc = ws_get(ctx, "gp_num", n * ELEM, &num))) return rc;
-  if ((rc = ws_get(ctx, "gp_den", n * ELEM, &den))) return rc;
+  if ((rc = ws_get(ctx, "gp_num", rows * ELEM, &num))) return rc;
+  if ((rc = ws_get(ctx, "gp_den", rows * ELEM, &den))) return rc;
   if ((rc = ws_get(ctx, "gp_bnum", nb * ELEM, &bn))) return rc;
   if ((rc = ws_get(ctx, "gp_bden", nb * ELEM, &bd))) return rc;
   const Fe beta_r2 = fe_mul(beta, fe_r2());
   {
-  ProfScope ps(ctx, s, "gp_terms_kernel", 288.0 * (double)n);   // 4 values + 4 indices + 4 gathers per row
-  hipLaunchKernelGGL(gp_terms_kernel, dim3((unsigned)nb), dim3(GP_THREADS), 0, s, cols, (uint64_t)n, beta, gamma, beta_r2,
-                     (uint64_t*)num, (uint64_t*)den, (uint64_t*)bn, (uint64_t*)bd, ctx->status_dev);
+    ProfScope ps(ctx, s, "gp_terms_kernel", 288.0 * (double)rows);   // 4 values + 4 indices + 4 gathers per row
+    hipLaunchKernelGGL(gp_terms_kernel, dim3((unsigned)nb), dim3(GP_THREADS), 0, s, cols, (uint64_t)n, (uint64_t)first, (uint64_t)rows,
+                       beta, gamma, beta_r2, (uint64_t*)num, (uint64_t*)den, (uint64_t*)bn, (uint64_t*)bd, ctx->status_dev);
   }
   HIP_TRY(ctx, hipGetLastError());
   {
-  ProfScope ps(ctx, s, "gp_block_scan_kernel", 0.0);
-  hipLaunchKernelGGL(gp_block_scan_kernel, dim3(1), dim3(GP_SCAN_THREADS), 0, s, (uint64_t*)bn, (uint64_t*)bd, (uint32_t)nb);
+    ProfScope ps(ctx, s, "gp_block_scan_kernel", 0.0);
+    hipLaunchKernelGGL(gp_block_scan_kernel, dim3(1), dim3(GP_SCAN_THREADS), 0, s, (uint64_t*)bn, (uint64_t*)bd, (uint32_t)nb, totals);
   }
   HIP_TRY(ctx, hipGetLastError());
-  {
-  ProfScope ps(ctx, s, "gp_finish_kernel", 32.0 * (double)(n + 1));   // the z column
-  hipLaunchKernelGGL(gp_finish_kernel, dim3((unsigned)nb), dim3(GP_THREADS), 0, s, (const uint64_t*)num, (const uint64_t*)den,
-                     (uint64_t)n, (const uint64_t*)bn, (const uint64_t*)bd, z_out);
-  }
+  ctx->gp_rows = rows;
+  return PLK_OK;
+}
+
+// carries of the other ranges (totals_all: 2 * ranges elements, device) into this range's block scans
+int gp_apply_carries(plk_ctx* ctx, hipStream_t s, const uint64_t* totals_all, size_t ranges, size_t mine) {
+  if (!totals_all || mine >= ranges || ranges > 4096) return fail(ctx, PLK_ERR_ARG, "bad range table");
+  const size_t nb = (ctx->gp_rows + GP_BLOCK_ROWS - 1) / GP_BLOCK_ROWS;
+  ProfScope ps(ctx, s, "gp_carry_kernel", 0.0);
+  hipLaunchKernelGGL(gp_carry_kernel, dim3(1), dim3(GP_THREADS), 0, s, totals_all, (uint32_t)ranges, (uint32_t)mine,
+                     (uint64_t*)ctx->ws["gp_bnum"].p, (uint64_t*)ctx->ws["gp_bden"].p, (uint32_t)nb);
   HIP_TRY(ctx, hipGetLastError());
   return PLK_OK;
+}
+
+// second half: z_after[i] = z[first + i + 1] for the range's rows; z0 (may be null) receives z[0] = 1
+int gp_finish(plk_ctx* ctx, hipStream_t s, uint64_t* z_after, uint64_t* z0) {
+  if (!z_after) return fail(ctx, PLK_ERR_ARG, "null pointer");
+  const size_t rows = ctx->gp_rows;
+  const size_t nb = (rows + GP_BLOCK_ROWS - 1) / GP_BLOCK_ROWS;
+  ProfScope ps(ctx, s, "gp_finish_kernel", 32.0 * (double)(rows + 1));   // the z column
+  hipLaunchKernelGGL(gp_finish_kernel, dim3((unsigned)nb), dim3(GP_THREADS), 0, s, (const uint64_t*)ctx->ws["gp_num"].p,
+                     (const uint64_t*)ctx->ws["gp_den"].p, (uint64_t)rows, (const uint64_t*)ctx->ws["gp_bnum"].p,
+                     (const uint64_t*)ctx->ws["gp_bden"].p, z_after, z0);
+  HIP_TRY(ctx, hipGetLastError());
+  return PLK_OK;
+}
+
+int launch_grand_product(plk_ctx* ctx, hipStream_t s, const uint64_t* const wires[4], const uint64_t* const sigma[4],
+                         size_t n, const uint64_t beta_[4], const uint64_t gamma_[4], uint64_t* z_out) {
+  if (!z_out || !beta_ || !gamma_) return fail(ctx, PLK_ERR_ARG, "null pointer");
+  if (n == 0) {  // z = [1]
+    const Fe one = fe_one();
+    HIP_TRY(ctx, hipMemcpyAsync(z_out, &one, ELEM, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return PLK_OK;
+  }
+  int rc;
+  if ((rc = gp_local(ctx, s, wires, sigma, n, 0, n, beta_, gamma_, nullptr))) return rc;
+  return gp_finish(ctx, s, z_out + 4, z_out);
 }
 
 int launch_gate_eval(plk_ctx* ctx, hipStream_t s, const uint64_t* const w[4], const uint64_t* const sel[9], size_t N,
@@ -802,6 +835,23 @@ int plk_dev_grand_product(plk_ctx* ctx, void* stream, const uint64_t* const wire
   if (rc) return rc;
   if (!wires || !sigma) return fail(ctx, PLK_ERR_ARG, "null pointer table");
   return launch_grand_product(ctx, (hipStream_t)stream, wires, sigma, n, beta, gamma, z_out);
+}
+
+int plk_dev_grand_product_local(plk_ctx* ctx, void* stream, const uint64_t* const wires[4], const uint64_t* const sigma[4], size_t n,
+                                size_t first, size_t rows, const uint64_t beta[4], const uint64_t gamma[4], uint64_t* totals_out) {
+  int rc = use_device(ctx);
+  if (rc) return rc;
+  if (!wires || !sigma || !totals_out) return fail(ctx, PLK_ERR_ARG, "null pointer");
+  return gp_local(ctx, (hipStream_t)stream, wires, sigma, n, first, rows, beta, gamma, totals_out);
+}
+
+int plk_dev_grand_product_finish(plk_ctx* ctx, void* stream, size_t rows, const uint64_t* totals_all, size_t ranges, size_t mine,
+                                 uint64_t* z_after_out) {
+  int rc = use_device(ctx);
+  if (rc) return rc;
+  if (rows == 0 || rows != ctx->gp_rows) return fail(ctx, PLK_ERR_ARG, "rows differ from the preceding plk_dev_grand_product_local");
+  if ((rc = gp_apply_carries(ctx, (hipStream_t)stream, totals_all, ranges, mine))) return rc;
+  return gp_finish(ctx, (hipStream_t)stream, z_after_out, nullptr);
 }
 
 int plk_dev_gate_table_fill(plk_ctx* ctx, void* stream, const uint8_t* row_ops, const uint64_t* const node_ids[4], size_t n,

@@ -64,8 +64,11 @@ __device__ __forceinline__ Fe block_scan_mul(Fe v, Fe* lds, Fe* total) {
   return fe_mul(v, carry);
 }
 
-// Kernel 1: per-row numerator / denominator terms and per-block products.
-__global__ __launch_bounds__(GP_THREADS) void gp_terms_kernel(GpCols cols, uint64_t n, Fe beta, Fe gamma, Fe beta_r2,
+// Kernel 1: per-row numerator / denominator terms and per-block products, for the rows
+// [first, first + rows) of an n-row circuit (the whole circuit: first = 0, rows = n).  num/den/block_*
+// are indexed from the range's first row; the gathers reach any row of the columns.
+__global__ __launch_bounds__(GP_THREADS) void gp_terms_kernel(GpCols cols, uint64_t n, uint64_t first, uint64_t rows,
+                                                              Fe beta, Fe gamma, Fe beta_r2,
                                                               uint64_t* num, uint64_t* den,
                                                               uint64_t* block_num, uint64_t* block_den,
                                                               GpStatus* status) {
@@ -74,8 +77,9 @@ __global__ __launch_bounds__(GP_THREADS) void gp_terms_kernel(GpCols cols, uint6
   Fe pn = fe_one(), pd = fe_one();
 #pragma unroll 1
   for (int it = 0; it < GP_ITEMS; ++it) {
-    const uint64_t j = row0 + it;
-    if (j >= n) break;
+    const uint64_t local = row0 + it;
+    if (local >= rows) break;
+    const uint64_t j = first + local;
     // beta * F::from(j): j as a raw integer times beta * R^2 / R
     Fe jraw = fe_zero(); jraw.l[0] = (uint32_t)j; jraw.l[1] = (uint32_t)(j >> 32);
     const Fe bj_g = fe_add(fe_mul(jraw, beta_r2), gamma);
@@ -92,8 +96,8 @@ __global__ __launch_bounds__(GP_THREADS) void gp_terms_kernel(GpCols cols, uint6
       dj = (k == 0) ? td : fe_mul(dj, td);
     }
     if (fe_is_zero(dj)) atomicMin(&status->zero_den_row, (unsigned long long)j);
-    fe_store(num, j, nj);
-    fe_store(den, j, dj);
+    fe_store(num, local, nj);
+    fe_store(den, local, dj);
     pn = fe_mul(pn, nj);
     pd = fe_mul(pd, dj);
   }
@@ -104,8 +108,11 @@ __global__ __launch_bounds__(GP_THREADS) void gp_terms_kernel(GpCols cols, uint6
 }
 
 // Kernel 2 (one workgroup): exclusive prefix of the block numerators, exclusive suffix of the
-// block denominators, and 1/D folded into the prefix.  In place.
-__global__ __launch_bounds__(GP_SCAN_THREADS) void gp_block_scan_kernel(uint64_t* block_num, uint64_t* block_den, uint32_t nb) {
+// block denominators, in place.  totals == nullptr: the range is the whole circuit and 1/D is
+// folded into the prefix here.  Otherwise the range's two products go to totals[0], totals[1] and
+// the inversion waits for gp_carry_kernel, which sees every range's totals.
+__global__ __launch_bounds__(GP_SCAN_THREADS) void gp_block_scan_kernel(uint64_t* block_num, uint64_t* block_den, uint32_t nb,
+                                                                        uint64_t* totals) {
   __shared__ Fe lds[GP_SCAN_THREADS / 64];
   __shared__ Fe inv_total;
   const uint32_t per = (nb + GP_SCAN_THREADS - 1) / GP_SCAN_THREADS;
@@ -116,7 +123,10 @@ __global__ __launch_bounds__(GP_SCAN_THREADS) void gp_block_scan_kernel(uint64_t
   Fe tot_n, tot_d;
   const Fe inc_n = block_scan_mul<GP_SCAN_THREADS, false>(pn, lds, &tot_n);
   const Fe inc_d = block_scan_mul<GP_SCAN_THREADS, true>(pd, lds, &tot_d);
-  if (threadIdx.x == 0) inv_total = fe_inverse_eea(tot_d);   // zero stays zero; the status word carries the error
+  if (threadIdx.x == 0) {
+    if (totals) { fe_store(totals, 0, tot_n); fe_store(totals, 1, tot_d); inv_total = fe_one(); }
+    else inv_total = fe_inverse_eea(tot_d);                  // zero stays zero; the status word carries the error
+  }
   __syncthreads();
   // exclusive carries of this thread's chunk: inclusive result with the own chunk divided out is
   // not available (no division), so rebuild them from the neighbours' inclusive values
@@ -137,9 +147,10 @@ __global__ __launch_bounds__(GP_SCAN_THREADS) void gp_block_scan_kernel(uint64_t
 }
 
 // Kernel 3: in-block prefix / suffix scans combined with the block carries -> z[1..n]; z[0] = 1.
+// z_after[local] = z[first + local + 1] for the range's rows; z0 (may be null) receives z[0] = 1.
 __global__ __launch_bounds__(GP_THREADS) void gp_finish_kernel(const uint64_t* num, const uint64_t* den, uint64_t n,
                                                                const uint64_t* block_num_ex, const uint64_t* block_den_ex,
-                                                               uint64_t* z) {
+                                                               uint64_t* z_after, uint64_t* z0) {
   __shared__ Fe lds[GP_THREADS / 64];
   __shared__ Fe edge[GP_THREADS / 64];
   const uint64_t row0 = ((uint64_t)blockIdx.x * GP_THREADS + threadIdx.x) * GP_ITEMS;
@@ -176,9 +187,35 @@ __global__ __launch_bounds__(GP_THREADS) void gp_finish_kernel(const uint64_t* n
     if (j >= n) break;
     const Fe p = fe_mul(cn, nv[it]);
     const Fe s = it + 1 < GP_ITEMS ? fe_mul(dv[it + 1], cd) : cd;
-    fe_store(z, j + 1, fe_mul(p, s));
+    fe_store(z_after, j, fe_mul(p, s));
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) fe_store(z, 0, fe_one());
+  if (z0 && blockIdx.x == 0 && threadIdx.x == 0) fe_store(z0, 0, fe_one());
+}
+
+// Row ranges on several GPUs: totals_all[2 g], totals_all[2 g + 1] = numerator and denominator
+// product of range g (ranges in row order).  Range `mine` needs, on top of its own scans,
+//   prefix carry = prod_{g < mine} numerator_g / D,   suffix carry = prod_{g > mine} denominator_g,
+// D = prod_g denominator_g: the one inversion, done by every range's owner on the same inputs.
+__global__ __launch_bounds__(GP_THREADS) void gp_carry_kernel(const uint64_t* totals_all, uint32_t ranges, uint32_t mine,
+                                                              uint64_t* block_num_ex, uint64_t* block_den_ex, uint32_t nb) {
+  __shared__ Fe carry[2];
+  if (threadIdx.x == 0) {
+    Fe cn = fe_one(), cd = fe_one(), all = fe_one();
+    for (uint32_t g = 0; g < ranges; ++g) {
+      const Fe d = fe_load(totals_all, 2 * g + 1);
+      all = fe_mul(all, d);
+      if (g < mine) cn = fe_mul(cn, fe_load(totals_all, 2 * g));
+      if (g > mine) cd = fe_mul(cd, d);
+    }
+    carry[0] = fe_mul(cn, fe_inverse_eea(all));
+    carry[1] = cd;
+  }
+  __syncthreads();
+  const Fe cn = carry[0], cd = carry[1];
+  for (uint32_t b = threadIdx.x; b < nb; b += GP_THREADS) {
+    fe_store(block_num_ex, b, fe_mul(fe_load(block_num_ex, b), cn));
+    fe_store(block_den_ex, b, fe_mul(fe_load(block_den_ex, b), cd));
+  }
 }
 
 }  // namespace plk

@@ -148,6 +148,23 @@ class DeviceProver:
                                                       b.ctypes.data_as(_lib.u64p), g.ctypes.data_as(_lib.u64p), _ptr(z)))
         return z
 
+    def grand_product_local(self, wires, sigma, n: int, first: int, rows: int, beta, gamma) -> torch.Tensor:
+        """First half of the grand product over the rows [first, first + rows): returns the `(2, 4)` tensor
+        (numerator product, denominator product) of the range; the scans stay in the context."""
+        totals = self.empty(2)
+        b, g = _host_fe(beta), _host_fe(gamma)
+        self.ctx.check(self.lib.plk_dev_grand_product_local(self.ctx.handle, self._stream(), _table(wires), _table(sigma), n, first, rows,
+                                                            b.ctypes.data_as(_lib.u64p), g.ctypes.data_as(_lib.u64p), _ptr(totals)))
+        return totals
+
+    def grand_product_finish(self, rows: int, totals_all: torch.Tensor, mine: int) -> torch.Tensor:
+        """Second half: `totals_all` is `(ranges, 2, 4)`; returns z[first + 1 .. first + rows] as `(rows, 4)`."""
+        out = self.empty(rows)
+        totals_all = totals_all.contiguous()
+        self.ctx.check(self.lib.plk_dev_grand_product_finish(self.ctx.handle, self._stream(), rows, _ptr(totals_all),
+                                                             totals_all.shape[0], mine, _ptr(out)))
+        return out
+
     def gate_constraint_chunk(self, wire_evals, sel_evals, count: int) -> torch.Tensor:
         out = self.empty(count)
         self.ctx.check(self.lib.plk_dev_gate_constraint_eval(self.ctx.handle, self._stream(), _table(wire_evals), _table(sel_evals),

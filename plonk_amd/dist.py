@@ -30,22 +30,40 @@ def _world(group=None):
     return 0, 1
 
 
+def _staged(t: torch.Tensor, group=None) -> bool:
+    """RCCL orders a collective on the current stream.  Any other backend given GPU tensors (gloo, used
+    to rehearse several ranks on one GPU) stages through host memory on a helper thread; with kernels
+    still in flight around it that hangs on this ROCm/PyTorch pair even without this library
+    (tools/gloo_a2a_probe.py ... heavy), so the device is drained on both sides."""
+    return t.is_cuda and dist.get_backend(group) != "nccl"
+
+
 def _all_to_all(send: torch.Tensor, group=None) -> torch.Tensor:
     """send[h] goes to rank h; returns recv with recv[g] = what rank g sent to us."""
     _, world = _world(group)
     if world == 1:
         return send
     recv = torch.empty_like(send)
-    # RCCL orders the exchange on the current stream.  Any other backend given GPU tensors (gloo, used
-    # to rehearse several ranks on one GPU) stages through host memory on a helper thread; with
-    # launches still in flight around it that was seen to hang, so the device is drained on both sides.
-    staged = send.is_cuda and dist.get_backend(group) != "nccl"
+    staged = _staged(send, group)
     if staged:
         torch.cuda.synchronize()
     dist.all_to_all_single(recv, send.contiguous(), group=group)
     if staged:
         torch.cuda.synchronize()
     return recv
+
+
+def _all_gather(t: torch.Tensor, group=None) -> List[torch.Tensor]:
+    """every rank's `t` (same shape everywhere), in rank order."""
+    _, world = _world(group)
+    out = [torch.empty_like(t) for _ in range(world)]
+    staged = _staged(t, group)
+    if staged:
+        torch.cuda.synchronize()
+    dist.all_gather(out, t.contiguous(), group=group)
+    if staged:
+        torch.cuda.synchronize()
+    return out
 
 
 def shard_circuits(num_circuits: int, group=None) -> List[int]:
@@ -104,6 +122,31 @@ def four_step_ntt(x_local: torch.Tensor, N: int, engine, group=None, inverse: bo
     return recv.view(N1, c2, 4).permute(1, 0, 2).contiguous().view(N // G, 4)   # [my k2][k1]
 
 
+def grand_product_sharded(engine, wires: Sequence[torch.Tensor], sigma: Sequence[torch.Tensor], n: int, beta, gamma,
+                          group=None) -> torch.Tensor:
+    """The grand product Z (n + 1 values, replicated on return) with the rows split over the ranks.
+    Every rank holds the whole columns (the numerator reads any row) and owns a contiguous block of
+    rows: local terms and scans -> all-gather of one (numerator, denominator) product pair per rank
+    (64 bytes each) -> carries and the one inversion, locally -> all-gather of the z blocks."""
+    rank, G = _world(group)
+    if G == 1 or n < G:
+        return engine.grand_product_cols(wires, sigma, n, beta, gamma)
+    per = (n + G - 1) // G
+    first = min(rank * per, n)
+    rows = min(per, n - first)
+    one = engine.grand_product_cols([w[:0] for w in wires], [s[:0] for s in sigma], 0, beta, gamma)   # z of no rows = [1]
+    if rows:
+        totals = engine.grand_product_local(wires, sigma, n, first, rows, beta, gamma)
+    else:                                          # a trailing rank without rows contributes the neutral pair
+        totals = torch.cat([one, one])
+    all_totals = _all_gather(totals, group)
+    block = torch.zeros((per, 4), dtype=totals.dtype, device=totals.device)
+    if rows:
+        block[:rows] = engine.grand_product_finish(rows, torch.stack(all_totals), rank)
+    blocks = _all_gather(block, group)
+    return torch.cat([one] + blocks)[:n + 1].contiguous()
+
+
 def assign_columns(num_columns: int, group=None) -> List[int]:
     """Columns (0..num_columns-1) this rank interpolates and extends in `round23_poly_sharded`."""
     rank, world = _world(group)
@@ -121,7 +164,7 @@ def round23_poly_sharded(engine, wires: Sequence[torch.Tensor], selectors: Seque
     if N % G:
         raise ValueError("ranks must divide the evaluation domain")
     chunk = N // G
-    z = engine.grand_product_cols(wires, sigma, n, beta, gamma)        # replicated: cheap next to the transforms
+    z = grand_product_sharded(engine, wires, sigma, n, beta, gamma, group)   # rows split over the ranks, z replicated
     cols: List[Optional[torch.Tensor]] = list(wires) + list(selectors) + list(sigma) + [z[:n]]
     kinds = [0] * 13 + [1] * 4 + [0]
     present = [i for i, c in enumerate(cols) if c is not None]

@@ -34,6 +34,14 @@ def main():
             got = pdist.four_step_ntt(to_device(x[lo:hi], d), N, eng, inverse=inverse)
             assert np.array_equal(to_host(got), want[lo:hi]), (log_n, inverse)
 
+    for rows_n in (1 << 12, 3001):               # even and uneven row blocks
+        cc = synth.make_circuit(1 << 12, circuit_id=5)
+        w_h = [w[:rows_n] for w in cc.table.wires()]
+        sg_h = [np.minimum(s[:rows_n], np.uint64(rows_n - 1)) for s in cc.perm.columns()]
+        z = pdist.grand_product_sharded(eng, [to_device(w, d) for w in w_h], [to_device(s, d) for s in sg_h], rows_n, cc.beta, cc.gamma)
+        eng.status()
+        assert np.array_equal(to_host(z), co.grand_product(w_h, sg_h, cc.beta, cc.gamma)), ("sharded grand product", rows_n)
+
     n, N = 1 << 10, 1 << 12
     c = synth.make_circuit(n, circuit_id=3)
     dc = eng.upload(c)

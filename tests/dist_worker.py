@@ -58,6 +58,14 @@ def main():
         assert np.array_equal(t2n(z), zr)
         assert np.array_equal(t2n(gate), gr[lo:hi]), "gate chunk"
         assert np.array_equal(t2n(perm), pr[lo:hi]), ("perm chunk", shift)
+    # the grand product alone, rows split over the ranks: even and uneven blocks, and fewer rows than ranks
+    for rows_n in (32, 27, 1):
+        cc = synth.make_circuit(32, circuit_id=9)
+        w_t = [n2t(w[:rows_n]) for w in cc.table.wires()]
+        sg = [np.minimum(s[:rows_n], np.uint64(rows_n - 1)) for s in cc.perm.columns()]
+        z = pdist.grand_product_sharded(eng, w_t, [n2t(s) for s in sg], rows_n, cc.beta, cc.gamma)
+        want = co.grand_product([w[:rows_n] for w in cc.table.wires()], sg, cc.beta, cc.gamma)
+        assert np.array_equal(t2n(z), want), ("sharded grand product", rows_n)
     # absent selector columns
     c2 = synth.make_circuit(n, circuit_id=8, kinds=("Add", "Mult", "Eq"))
     sels2 = [n2t(c2.table.selectors[k]) if k in c2.table.selectors else None for k in co.AST_KINDS]

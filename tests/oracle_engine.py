@@ -42,6 +42,39 @@ class OracleEngine:
     def grand_product_cols(self, wires, sigma, n, beta, gamma):
         return n2t(co.grand_product([t2n(w) for w in wires], [t2n(s).reshape(-1) for s in sigma], beta, gamma))
 
+    def _terms(self, wires, sigma, first, rows, beta, gamma):
+        w = [synth.mont_to_ints(t2n(x)) for x in wires]
+        sg = [[int(v) for v in t2n(s).reshape(-1)] for s in sigma]
+        b, g = synth.mont_to_ints(np.asarray(beta))[0], synth.mont_to_ints(np.asarray(gamma))[0]
+        num, den = [], []
+        for j in range(first, first + rows):
+            nj = dj = 1
+            for k in range(4):
+                nj = nj * (w[k][j] + b * w[k][sg[k][j]] + g) % po.P
+                dj = dj * (w[k][j] + b * j + g) % po.P
+            num.append(nj)
+            den.append(dj)
+        return num, den
+
+    def grand_product_local(self, wires, sigma, n, first, rows, beta, gamma):
+        self._gp = self._terms(wires, sigma, first, rows, beta, gamma)
+        tn = td = 1
+        for a, b in zip(*self._gp):
+            tn, td = tn * a % po.P, td * b % po.P
+        return n2t(synth.ints_to_mont([tn, td]))
+
+    def grand_product_finish(self, rows, totals_all, mine):
+        tot = synth.mont_to_ints(t2n(totals_all).reshape(-1, 4))      # [num_0, den_0, num_1, den_1, ...]
+        z = 1
+        for g in range(mine):                                          # z at the range's first row
+            z = z * tot[2 * g] % po.P * pow(tot[2 * g + 1], -1, po.P) % po.P
+        out = []
+        for a, b in zip(*self._gp):
+            z = z * a % po.P * pow(b, -1, po.P) % po.P
+            out.append(z)
+        assert len(out) == rows
+        return n2t(synth.ints_to_mont(out))
+
     def ntt_batch(self, cols, N, inverse=False, kinds=None):
         out = []
         for i, c in enumerate(cols):

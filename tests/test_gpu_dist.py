@@ -78,3 +78,22 @@ def test_ranks_share_the_gpu(world):
     r = subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS="2"), capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.count(" ok") == world
+
+
+@pytest.mark.parametrize("n,ranges", [(1 << 14, 4), (5000, 3), (1025, 2), (7, 7)])
+def test_grand_product_by_row_ranges(prover, n, ranges):
+    """plk_dev_grand_product_local / _finish on one GPU, range after range, against the serial recurrence."""
+    c = synth.make_circuit(1 << 14, circuit_id=11)
+    w_h = [w[:n] for w in c.table.wires()]
+    sg_h = [np.minimum(s[:n], np.uint64(n - 1)) for s in c.perm.columns()]
+    wires = [to_device(w, prover.device) for w in w_h]
+    sigma = [to_device(s, prover.device) for s in sg_h]
+    per = (n + ranges - 1) // ranges
+    bounds = [(min(g * per, n), min(per, n - min(g * per, n))) for g in range(ranges)]
+    totals = torch.stack([prover.grand_product_local(wires, sigma, n, f, r, c.beta, c.gamma) for f, r in bounds])
+    want = co.grand_product(w_h, sg_h, c.beta, c.gamma)
+    for g, (f, r) in enumerate(bounds):
+        prover.grand_product_local(wires, sigma, n, f, r, c.beta, c.gamma)
+        z_blk = prover.grand_product_finish(r, totals, g)
+        prover.status()
+        assert np.array_equal(to_host(z_blk), want[f + 1:f + 1 + r]), (g, f, r)
