@@ -63,6 +63,13 @@ long long plk_last_error_row(const plk_ctx* ctx);
 /* field constants, 4 limbs each: modulus (plain integer), one (= R mod p), R^2 mod p */
 void plk_field_constants(uint64_t modulus[4], uint64_t one[4], uint64_t r2[4]);
 
+/* Page-locked host memory for the columns passed to the host entry points.  They accept any host
+ * pointer; buffers from plk_host_alloc are copied to and from the GPU by DMA at PCIe speed, others
+ * go through the runtime's staging copies (measured 3-4x slower).  No counterpart in the reference
+ * (a Rust caller would back its Vec<F> with these through a custom allocator). */
+int plk_host_alloc(plk_ctx* ctx, size_t bytes, void** out);
+void plk_host_free(plk_ctx* ctx, void* p);
+
 /* ---- host entry points: the reference's seven functions ---------------------------------- */
 
 /* evaluations_to_dense_polynomial — src/polynomial_utils.rs:18-33.

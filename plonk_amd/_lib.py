@@ -44,6 +44,8 @@ SIGNATURES = {
     "plk_last_error": (C.c_char_p, [C.c_void_p]),
     "plk_last_error_row": (C.c_longlong, [C.c_void_p]),
     "plk_field_constants": (None, [u64p, u64p, u64p]),
+    "plk_host_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "plk_host_free": (None, [C.c_void_p, C.c_void_p]),
     "plk_intt": (C.c_int, [C.c_void_p, u64p, C.c_size_t, C.c_size_t, u64p]),
     "plk_build_and_convert": (C.c_int, [C.c_void_p, C.c_size_t, BUILDER_FN, C.c_void_p, u64p]),
     "plk_ntt": (C.c_int, [C.c_void_p, u64p, C.c_size_t, C.c_size_t, u64p]),

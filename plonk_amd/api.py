@@ -187,6 +187,17 @@ class Context:
             cls._default = cls(0)
         return cls._default
 
+    def pinned_empty(self, shape, dtype=np.uint64) -> np.ndarray:
+        """A numpy array in page-locked host memory (plk_host_alloc): the host entry points move such
+        arrays by DMA.  The memory is released when the array and every view of it are gone."""
+        import weakref
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        self.check(self.lib.plk_host_alloc(self.handle, nbytes, C.byref(p)))
+        buf = (C.c_uint8 * max(nbytes, 1)).from_address(p.value)
+        weakref.finalize(buf, self.lib.plk_host_free, self.handle, p)
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
     def check(self, rc: int):
         if rc == _lib.PLK_OK:
             return
@@ -374,8 +385,9 @@ def build_permutation_table(node_ids: Sequence[np.ndarray], ctx: Optional[Contex
 
 def prove_round23(evaluation_table: GateEvaluationTable, permutation_table: PermutationTable, beta: np.ndarray,
                   gamma: np.ndarray, n_domain: Radix2EvaluationDomain, evaluation_domain: Radix2EvaluationDomain,
-                  z_shift: int = 1, ctx: Optional[Context] = None):
-    """Rounds 2+3 in one device-resident call: returns (z [n+1], gate constraints [N], permutation constraints [N])."""
+                  z_shift: int = 1, ctx: Optional[Context] = None, out=None):
+    """Rounds 2+3 in one device-resident call: returns (z [n+1], gate constraints [N], permutation constraints [N]).
+    `out` may supply the three result arrays (e.g. from Context.pinned_empty)."""
     c = _ctx(ctx)
     wires = [_col(w, "wire") for w in evaluation_table.wires()]
     sels = _sel_cols(evaluation_table.selectors)
@@ -383,9 +395,15 @@ def prove_round23(evaluation_table: GateEvaluationTable, permutation_table: Perm
     n, N = n_domain.size(), evaluation_domain.size()
     if any(a.shape[0] != n for a in wires + sig + [s for s in sels if s is not None]):
         raise LengthMismatch(_lib.PLK_ERR_LENGTH, "Evaluation length must match the domain size")
-    z = np.empty((n + 1, 4), dtype=np.uint64)
-    g_out = np.empty((N, 4), dtype=np.uint64)
-    p_out = np.empty((N, 4), dtype=np.uint64)
+    if out is not None:
+        z, g_out, p_out = out
+        if (z.shape, g_out.shape, p_out.shape) != ((n + 1, 4), (N, 4), (N, 4)) or not all(
+                a.dtype == np.uint64 and a.flags.c_contiguous for a in out):
+            raise ValueError("out: contiguous uint64 arrays of shapes (n + 1, 4), (N, 4), (N, 4) expected")
+    else:
+        z = np.empty((n + 1, 4), dtype=np.uint64)
+        g_out = np.empty((N, 4), dtype=np.uint64)
+        p_out = np.empty((N, 4), dtype=np.uint64)
     b, g = _fe(beta), _fe(gamma)
     c.check(c.lib.plk_round23(c.handle, _table(wires), _table(sels), _table(sig), n, N, _p(b), _p(g), z_shift,
                               _p(z), _p(g_out), _p(p_out)))

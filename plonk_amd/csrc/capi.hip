@@ -657,17 +657,15 @@ int fetch_status(plk_ctx* ctx, hipStream_t s) {
 
 // ---- host staging helpers
 
+// Device copies of a host entry point's arguments and results.  The buffers are slots of the
+// context's grow-only workspace ("stage0", "stage1", ... in order of use), so a repeated call of the
+// same shape allocates nothing; they are valid until the next host entry point on this context.
 struct Staged {
   plk_ctx* ctx;
-  std::vector<void*> bufs;
+  int used = 0;
   explicit Staged(plk_ctx* c) : ctx(c) {}
-  ~Staged() { for (void* p : bufs) (void)hipFree(p); }
   int alloc(size_t bytes, void** out) {
-    void* p = nullptr;
-    HIP_TRY(ctx, hipMalloc(&p, std::max<size_t>(bytes, 32)));
-    bufs.push_back(p);
-    *out = p;
-    return PLK_OK;
+    return ws_get(ctx, "stage" + std::to_string(used++), std::max<size_t>(bytes, 32), out);
   }
   int upload(const void* host, size_t bytes, void** out) {
     int rc = alloc(bytes, out);
@@ -747,6 +745,21 @@ void plk_ctx_destroy(plk_ctx* ctx) {
   if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
+}
+
+int plk_host_alloc(plk_ctx* ctx, size_t bytes, void** out) {
+  int rc = use_device(ctx);
+  if (rc) return rc;
+  if (!out) return fail(ctx, PLK_ERR_ARG, "null pointer");
+  *out = nullptr;
+  HIP_TRY(ctx, hipHostMalloc(out, std::max<size_t>(bytes, 64), hipHostMallocDefault));
+  return PLK_OK;
+}
+
+void plk_host_free(plk_ctx* ctx, void* p) {
+  if (!ctx || !p) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipHostFree(p);
 }
 
 const char* plk_strerror(int code) {
