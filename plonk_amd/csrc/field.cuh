@@ -184,6 +184,147 @@ __host__ __device__ inline Fe fe_inverse_eea(const Fe& a) {
   return is_one(u) ? b : c;
 }
 
+// ---- inversion by the binary GCD with batched steps (Pornin, "Optimized Binary GCD for Modular
+// Inversion", 2020): 31 steps at a time are decided on 64-bit approximations (top 33 bits and low
+// 31 bits of the two running values), and their combined effect - two small signed factors per
+// value - is applied to the full-width numbers once.  About a sixth of the instructions of the
+// bit-at-a-time loop above; same result (the inverse is unique).  Takes and returns Montgomery form.
+namespace bingcd {
+
+__host__ __device__ __forceinline__ uint64_t mulhi64(uint64_t a, uint64_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umul64hi(a, b);
+#else
+  return (uint64_t)(((unsigned __int128)a * b) >> 64);
+#endif
+}
+
+// r[0..4] = x[0..3] * m
+__host__ __device__ __forceinline__ void mul_small(const uint64_t x[4], uint64_t m, uint64_t r[5]) {
+  uint64_t carry = 0;
+  for (int i = 0; i < 4; ++i) {
+    uint64_t lo = x[i] * m, hi = mulhi64(x[i], m);
+    lo += carry;
+    hi += lo < carry;
+    r[i] = lo;
+    carry = hi;
+  }
+  r[4] = carry;
+}
+
+__host__ __device__ __forceinline__ void add5(uint64_t r[5], const uint64_t t[5]) {
+  uint64_t c = 0;
+  for (int i = 0; i < 5; ++i) {
+    const uint64_t s = r[i] + t[i], s2 = s + c;
+    c = (uint64_t)(s < r[i]) | (uint64_t)(s2 < s);
+    r[i] = s2;
+  }
+}
+
+__host__ __device__ __forceinline__ void neg5(uint64_t r[5]) {
+  uint64_t c = 1;
+  for (int i = 0; i < 5; ++i) { const uint64_t s = ~r[i] + c; c = (c && s == 0) ? 1 : 0; r[i] = s; }
+}
+
+__host__ __device__ __forceinline__ int bitlen4(const uint64_t x[4]) {
+  for (int i = 3; i >= 0; --i)
+    if (x[i]) return 64 * i + 64 - __builtin_clzll(x[i]);
+  return 0;
+}
+
+// bits [s, s + 64) of x (zero beyond bit 255)
+__host__ __device__ __forceinline__ uint64_t bits_from(const uint64_t x[4], int s) {
+  const int limb = s >> 6, off = s & 63;
+  uint64_t v = x[limb] >> off;
+  if (off && limb + 1 < 4) v |= x[limb + 1] << (64 - off);
+  return v;
+}
+
+// x <- |f x + g y| / 2^31 (the division is exact); returns true if the sign was flipped
+__host__ __device__ __forceinline__ bool lincomb_div(uint64_t out[4], const uint64_t x[4], int64_t f, const uint64_t y[4], int64_t g) {
+  uint64_t r[5], t[5];
+  mul_small(x, (uint64_t)(f < 0 ? -f : f), r);
+  if (f < 0) neg5(r);
+  mul_small(y, (uint64_t)(g < 0 ? -g : g), t);
+  if (g < 0) neg5(t);
+  add5(r, t);
+  const bool negative = (r[4] >> 63) != 0;
+  if (negative) neg5(r);
+  for (int i = 0; i < 4; ++i) out[i] = (r[i] >> 31) | (r[i + 1] << 33);
+  return negative;
+}
+
+// out <- (f u + g v) / 2^31 mod p, u, v in [0, p); p = 1 mod 2^32, so the Montgomery factor is -t mod 2^31
+__host__ __device__ __forceinline__ void lincomb_mod(uint64_t out[4], const uint64_t u[4], int64_t f, const uint64_t v[4], int64_t g,
+                                                     const uint64_t p[4]) {
+  uint64_t a[4], b[4], r[5], t[5];
+  auto p_minus = [&](const uint64_t x[4], uint64_t o[4]) {   // p - x
+    uint64_t bo = 0;
+    for (int i = 0; i < 4; ++i) { const uint64_t d = p[i] - x[i], d2 = d - bo; bo = (uint64_t)(p[i] < x[i]) | (uint64_t)(d < bo); o[i] = d2; }
+  };
+  if (f < 0) p_minus(u, a); else for (int i = 0; i < 4; ++i) a[i] = u[i];
+  if (g < 0) p_minus(v, b); else for (int i = 0; i < 4; ++i) b[i] = v[i];
+  mul_small(a, (uint64_t)(f < 0 ? -f : f), r);
+  mul_small(b, (uint64_t)(g < 0 ? -g : g), t);
+  add5(r, t);
+  mul_small(p, (0 - r[0]) & 0x7fffffffull, t);
+  add5(r, t);                                       // now a multiple of 2^31, below 3 p 2^31
+  uint64_t o[4];
+  for (int i = 0; i < 4; ++i) o[i] = (r[i] >> 31) | (r[i + 1] << 33);
+  for (int pass = 0; pass < 2; ++pass) {            // into [0, p)
+    uint64_t d[4], bo = 0;
+    for (int i = 0; i < 4; ++i) { const uint64_t e = o[i] - p[i], e2 = e - bo; bo = (uint64_t)(o[i] < p[i]) | (uint64_t)(e < bo); d[i] = e2; }
+    if (!bo) for (int i = 0; i < 4; ++i) o[i] = d[i];
+  }
+  for (int i = 0; i < 4; ++i) out[i] = o[i];
+}
+
+}  // namespace bingcd
+
+__host__ __device__ inline Fe fe_inverse_bingcd(const Fe& x) {
+  using namespace bingcd;
+  if (fe_is_zero(x)) return x;
+  uint64_t a[4], b[4], u[4], v[4], p[4];
+  for (int i = 0; i < 4; ++i) {
+    a[i] = (uint64_t)x.l[2 * i] | ((uint64_t)x.l[2 * i + 1] << 32);
+    p[i] = (uint64_t)Field::P[2 * i] | ((uint64_t)Field::P[2 * i + 1] << 32);
+    b[i] = p[i];
+    u[i] = (uint64_t)Field::R2[2 * i] | ((uint64_t)Field::R2[2 * i + 1] << 32);   // x = a R: R^2 / x = R / a
+    v[i] = 0;
+  }
+  // invariants: a = u x / R^2, b = v x / R^2 (mod p); gcd(a, b) = 1; ends with a = 0, b = 1
+  for (int round = 0; round < 40 && (a[0] | a[1] | a[2] | a[3]); ++round) {
+    const int la = bitlen4(a), lb = bitlen4(b), n = la > lb ? la : lb;
+    uint64_t xa, xb;
+    if (n <= 64) { xa = a[0]; xb = b[0]; }
+    else {
+      xa = (bits_from(a, n - 33) << 31) | (a[0] & 0x7fffffffull);
+      xb = (bits_from(b, n - 33) << 31) | (b[0] & 0x7fffffffull);
+    }
+    int64_t f0 = 1, g0 = 0, f1 = 0, g1 = 1;
+    for (int i = 0; i < 31; ++i) {
+      if (xa & 1) {
+        if (xa < xb) {
+          const uint64_t tx = xa; xa = xb; xb = tx;
+          int64_t ts = f0; f0 = f1; f1 = ts;
+          ts = g0; g0 = g1; g1 = ts;
+        }
+        xa -= xb; f0 -= f1; g0 -= g1;
+      }
+      xa >>= 1; f1 <<= 1; g1 <<= 1;
+    }
+    uint64_t na[4], nb[4], nu[4], nv[4];
+    if (lincomb_div(na, a, f0, b, g0)) { f0 = -f0; g0 = -g0; }
+    if (lincomb_div(nb, a, f1, b, g1)) { f1 = -f1; g1 = -g1; }
+    lincomb_mod(nu, u, f0, v, g0, p);
+    lincomb_mod(nv, u, f1, v, g1, p);
+    for (int i = 0; i < 4; ++i) { a[i] = na[i]; b[i] = nb[i]; u[i] = nu[i]; v[i] = nv[i]; }
+  }
+  Fe r;
+  for (int i = 0; i < 4; ++i) { r.l[2 * i] = (uint32_t)v[i]; r.l[2 * i + 1] = (uint32_t)(v[i] >> 32); }
+  return r;
+}
+
 // ---- global / LDS access helpers: an element is two 16-byte halves
 __device__ __forceinline__ Fe fe_load(const uint64_t* base, size_t idx) {
   const uint4* p = reinterpret_cast<const uint4*>(base) + 2 * idx;

@@ -53,15 +53,24 @@ __device__ __forceinline__ Fe block_scan_mul(Fe v, Fe* lds, Fe* total) {
   }
   if (lane == (REVERSE ? 0 : 63)) lds[wave] = v;
   __syncthreads();
-  Fe carry = fe_one(), all = fe_one();
-  for (int w = 0; w < WAVES; ++w) {
-    const Fe t = lds[w];
-    all = fe_mul(all, t);
-    if (REVERSE ? (w > wave) : (w < wave)) carry = fe_mul(carry, t);
+  // second level: the first wave scans the WAVES wave totals the same way, in place
+  if (wave == 0) {
+    Fe t = lane < WAVES ? lds[lane] : fe_one();
+#pragma unroll
+    for (int d = 1; d < WAVES; d <<= 1) {
+      const int src = REVERSE ? lane + d : lane - d;
+      const Fe o = fe_shfl(t, src & 63);
+      if (REVERSE ? (src < WAVES) : (src >= 0)) t = fe_mul(t, o);
+    }
+    if (lane < WAVES) lds[lane] = t;
   }
   __syncthreads();
-  *total = all;
-  return fe_mul(v, carry);
+  *total = lds[REVERSE ? 0 : WAVES - 1];
+  const int prev = REVERSE ? wave + 1 : wave - 1;
+  const bool has_carry = REVERSE ? (prev < WAVES) : (prev >= 0);
+  const Fe carry = lds[has_carry ? prev : 0];
+  __syncthreads();
+  return has_carry ? fe_mul(v, carry) : v;
 }
 
 // Kernel 1: per-row numerator / denominator terms and per-block products, for the rows
@@ -125,7 +134,7 @@ __global__ __launch_bounds__(GP_SCAN_THREADS) void gp_block_scan_kernel(uint64_t
   const Fe inc_d = block_scan_mul<GP_SCAN_THREADS, true>(pd, lds, &tot_d);
   if (threadIdx.x == 0) {
     if (totals) { fe_store(totals, 0, tot_n); fe_store(totals, 1, tot_d); inv_total = fe_one(); }
-    else inv_total = fe_inverse_eea(tot_d);                  // zero stays zero; the status word carries the error
+    else inv_total = fe_inverse_bingcd(tot_d);               // zero stays zero; the status word carries the error
   }
   __syncthreads();
   // exclusive carries of this thread's chunk: inclusive result with the own chunk divided out is
@@ -207,7 +216,7 @@ __global__ __launch_bounds__(GP_THREADS) void gp_carry_kernel(const uint64_t* to
       if (g < mine) cn = fe_mul(cn, fe_load(totals_all, 2 * g));
       if (g > mine) cd = fe_mul(cd, d);
     }
-    carry[0] = fe_mul(cn, fe_inverse_eea(all));
+    carry[0] = fe_mul(cn, fe_inverse_bingcd(all));
     carry[1] = cd;
   }
   __syncthreads();

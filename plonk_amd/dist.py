@@ -31,10 +31,10 @@ def _world(group=None):
 
 
 def _staged(t: torch.Tensor, group=None) -> bool:
-    """RCCL orders a collective on the current stream.  Any other backend given GPU tensors (gloo, used
-    to rehearse several ranks on one GPU) stages through host memory on a helper thread; with kernels
-    still in flight around it that hangs on this ROCm/PyTorch pair even without this library
-    (tools/gloo_a2a_probe.py ... heavy), so the device is drained on both sides."""
+    """RCCL runs a collective on GPU tensors in stream order.  Any other backend (gloo, used to rehearse
+    several ranks on one GPU) is given host copies instead: its own handling of GPU tensors hangs
+    on this ROCm/PyTorch pair whenever kernels are in flight, with or without this library
+    (tools/gloo_a2a_probe.py ... heavy), and now and then even on an idle device."""
     return t.is_cuda and dist.get_backend(group) != "nccl"
 
 
@@ -43,26 +43,26 @@ def _all_to_all(send: torch.Tensor, group=None) -> torch.Tensor:
     _, world = _world(group)
     if world == 1:
         return send
+    if _staged(send, group):
+        host = send.contiguous().cpu()
+        recv = torch.empty_like(host)
+        dist.all_to_all_single(recv, host, group=group)
+        return recv.to(send.device)
     recv = torch.empty_like(send)
-    staged = _staged(send, group)
-    if staged:
-        torch.cuda.synchronize()
     dist.all_to_all_single(recv, send.contiguous(), group=group)
-    if staged:
-        torch.cuda.synchronize()
     return recv
 
 
 def _all_gather(t: torch.Tensor, group=None) -> List[torch.Tensor]:
     """every rank's `t` (same shape everywhere), in rank order."""
     _, world = _world(group)
+    if _staged(t, group):
+        host = t.contiguous().cpu()
+        out = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(out, host, group=group)
+        return [o.to(t.device) for o in out]
     out = [torch.empty_like(t) for _ in range(world)]
-    staged = _staged(t, group)
-    if staged:
-        torch.cuda.synchronize()
     dist.all_gather(out, t.contiguous(), group=group)
-    if staged:
-        torch.cuda.synchronize()
     return out
 
 
