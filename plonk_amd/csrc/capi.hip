@@ -497,6 +497,13 @@ int launch_round23(plk_ctx* ctx, hipStream_t s, const uint64_t* const wires[4], 
     hipStream_t sa = ctx->aux;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, s));
     HIP_TRY(ctx, hipStreamWaitEvent(sa, ctx->ev_fork, 0));
+    // whatever happens below, `s` is made to wait for the side stream before this function returns
+    struct Join {
+      plk_ctx* ctx; hipStream_t s, sa; bool recorded = false, joined = false;
+      void record() { if (!recorded) { (void)hipEventRecord(ctx->ev_join, sa); recorded = true; } }
+      void join() { record(); if (!joined) { (void)hipStreamWaitEvent(s, ctx->ev_join, 0); joined = true; } }
+      ~Join() { join(); }
+    } side{ctx, s, sa};
     if ((rc = launch_grand_product(ctx, sa, wires, sigma, n, beta, gamma, z))) return rc;
     {
       const uint64_t* zin[1] = {z}; uint64_t* zc[1] = {col_coef(17)}; uint64_t* ze[1] = {col_cos(17)};
@@ -504,7 +511,7 @@ int launch_round23(plk_ctx* ctx, hipStream_t s, const uint64_t* const wires[4], 
       const uint64_t* zci[1] = {col_coef(17)};
       if ((rc = launch_ntt(ctx, sa, zci, nullptr, 1, n, n, false, ze, 0, 0, 3, "ntt_tmp_aux"))) return rc;
     }
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_join, sa));
+    side.record();
     for (int k = 0; k < 4; ++k) { in[m] = wires[k]; kinds[m] = NTT_IN_FIELD; col_of[m] = k; ++m; }
     for (int k = 0; k < 9; ++k) if (sel && sel[k]) { in[m] = sel[k]; kinds[m] = NTT_IN_FIELD; col_of[m] = 4 + k; ++m; }
     for (int k = 0; k < 4; ++k) { in[m] = sigma[k]; kinds[m] = NTT_IN_U64; col_of[m] = 13 + k; ++m; }
@@ -522,7 +529,7 @@ int launch_round23(plk_ctx* ctx, hipStream_t s, const uint64_t* const wires[4], 
                          (uint64_t)n, gate_out);
       HIP_TRY(ctx, hipGetLastError());
     }
-    HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
+    side.join();
     if (perm_out) {
       const Fe fb = fe_from_limbs64(beta), fg = fe_from_limbs64(gamma);
       PermColsCoset pc{};
