@@ -167,6 +167,20 @@ int plk_gate_table_fill(plk_ctx* ctx, const uint8_t* row_ops, const uint64_t* co
 int plk_dev_ntt_batch(plk_ctx* ctx, void* stream, const uint64_t* const* in, const uint32_t* kinds, size_t batch,
                       size_t n_in, size_t N, int inverse, uint64_t* const* out);
 
+/* Interpolation + evaluation on the 4n-point domain in one call, for `batch` columns of n rows:
+ * evaluations_to_dense_polynomial (src/polynomial_utils.rs:18-33) followed by
+ * evaluate_over_domain_by_ref on the domain of size 4n (src/execution_trace.rs:362-370), natural
+ * order.  The 4n-point domain is four cosets of the trace domain: the coset of the trace domain
+ * itself repeats the input column, the other three are n-point transforms of prescaled
+ * coefficients - the same values as plk_dev_ntt_batch(coeffs, n, 4n) for about 3/4 of the work.
+ * coef_out may be NULL, or hold NULL entries, where the coefficients are not wanted.
+ * Output layout (for splitting the 4n points over GPUs): with chunk != 0, point i is written at
+ * eval_out[b] + (i / chunk) * chunk_stride + i % chunk, and every chunk is followed by copies of the
+ * first `halo` points of the next chunk, cyclically (chunk divides 4n, chunk_stride >= chunk + halo);
+ * chunk = 0 writes the plain 4n-element vector. */
+int plk_dev_extend4(plk_ctx* ctx, void* stream, const uint64_t* const* cols, const uint32_t* kinds, size_t batch, size_t n,
+                    uint64_t* const* coef_out, uint64_t* const* eval_out, size_t chunk, size_t chunk_stride, size_t halo);
+
 /* Same transform over `count` equally spaced columns: column b is read at in + b * in_stride and
  * written at out + b * out_stride (strides in elements, >= n_in and >= N).  This is the shape of
  * the row / column phases of a four-step transform on a matrix held in HBM. */

@@ -338,6 +338,44 @@ int launch_ntt(plk_ctx* ctx, hipStream_t s, const uint64_t* const* in, const uin
   return PLK_OK;
 }
 
+// Interpolation of `batch` columns (n rows, kinds as in launch_ntt) and their evaluations on the
+// 4n-point domain in natural order: coefficients to coef_out[b] (n elements, may be null pointers'
+// table = not wanted), evaluations to eval_out[b] (4n elements).  The three cosets beyond the trace
+// domain are n-point transforms; the trace-domain points are the input column itself.
+int launch_extend4(plk_ctx* ctx, hipStream_t s, const uint64_t* const* cols, const uint32_t* kinds, size_t batch, size_t n,
+                   uint64_t* const* coef_out, uint64_t* const* eval_out, size_t chunk, size_t chunk_stride, size_t halo) {
+  int rc, log_n;
+  if ((rc = check_domain(ctx, n, &log_n))) return rc;
+  if (log_n < 2 || log_n + 2 > Field::TWO_ADICITY) return fail(ctx, PLK_ERR_TWO_ADICITY, "extension needs 4 <= n and 4n within the two-adicity");
+  if (batch == 0) return PLK_OK;
+  if (batch > NTT_MAX_BATCH) return fail(ctx, PLK_ERR_ARG, "batch exceeds PLK_MAX_BATCH");
+  if (chunk == 0) { chunk = 4 * n; chunk_stride = 4 * n; halo = 0; }
+  if ((4 * n) % chunk || halo > chunk || chunk_stride < chunk + halo) return fail(ctx, PLK_ERR_ARG, "bad chunk layout");
+  void *cp, *pp;
+  if ((rc = ws_get(ctx, "ext_coef", batch * n * ELEM, &cp))) return rc;
+  if ((rc = ws_get(ctx, "ext_planes", batch * 3 * n * ELEM, &pp))) return rc;
+  uint64_t* coef[NTT_MAX_BATCH]; const uint64_t* coef_in[NTT_MAX_BATCH]; uint64_t* planes[NTT_MAX_BATCH];
+  Interleave4Args a{};
+  for (size_t b = 0; b < batch; ++b) {
+    if (!cols[b] || !eval_out[b]) return fail(ctx, PLK_ERR_ARG, "null column pointer");
+    coef[b] = (coef_out && coef_out[b]) ? coef_out[b] : (uint64_t*)cp + b * n * 4;
+    coef_in[b] = coef[b];
+    planes[b] = (uint64_t*)pp + b * 3 * n * 4;
+    a.plane0[b] = cols[b];
+    a.raw_index[b] = kinds && kinds[b] == NTT_IN_U64;
+    a.out[b] = eval_out[b];
+  }
+  a.planes = (const uint64_t*)pp;
+  a.chunk = chunk; a.chunk_stride = chunk_stride; a.halo = halo;
+  if ((rc = launch_ntt(ctx, s, cols, kinds, batch, n, n, true, coef))) return rc;
+  if ((rc = launch_ntt(ctx, s, coef_in, nullptr, batch, n, n, false, planes, 0, 0, 3))) return rc;
+  ProfScope ps(ctx, s, "interleave4_kernel", 2.0 * 128.0 * (double)n * (double)batch);
+  hipLaunchKernelGGL(interleave4_kernel, dim3((unsigned)((4 * n + EW_THREADS - 1) / EW_THREADS), (unsigned)batch), dim3(EW_THREADS), 0, s, a,
+                     (uint64_t)n);
+  HIP_TRY(ctx, hipGetLastError());
+  return PLK_OK;
+}
+
 int status_reset(plk_ctx* ctx, hipStream_t s) {
   HIP_TRY(ctx, hipMemsetAsync(ctx->status_dev, 0xff, sizeof(GpStatus), s));
   return PLK_OK;
@@ -923,6 +961,20 @@ int plk_dev_round23(plk_ctx* ctx, void* stream, const uint64_t* const wires[4], 
   if (rc) return rc;
   if (!wires || !sigma) return fail(ctx, PLK_ERR_ARG, "null pointer table");
   return launch_round23(ctx, (hipStream_t)stream, wires, sel, sigma, n, N, beta, gamma, z_shift, z_out, gate_out, perm_out);
+}
+
+int plk_dev_extend4(plk_ctx* ctx, void* stream, const uint64_t* const* cols, const uint32_t* kinds, size_t batch, size_t n,
+                    uint64_t* const* coef_out, uint64_t* const* eval_out, size_t chunk, size_t chunk_stride, size_t halo) {
+  int rc = use_device(ctx);
+  if (rc) return rc;
+  if (!cols || !eval_out) return fail(ctx, PLK_ERR_ARG, "null pointer table");
+  for (size_t done = 0; done < batch; done += NTT_MAX_BATCH) {
+    const size_t m = std::min<size_t>(NTT_MAX_BATCH, batch - done);
+    if ((rc = launch_extend4(ctx, (hipStream_t)stream, cols + done, kinds ? kinds + done : nullptr, m, n, coef_out ? coef_out + done : nullptr,
+                             eval_out + done, chunk, chunk_stride, halo)))
+      return rc;
+  }
+  return PLK_OK;
 }
 
 int plk_dev_ntt_strided(plk_ctx* ctx, void* stream, const uint64_t* in, size_t in_stride, uint32_t kind, size_t count,

@@ -150,6 +150,37 @@ __global__ __launch_bounds__(EW_THREADS) void perm_constraint_kernel(PermCols co
   fe_store(out, i, e);
 }
 
+// Natural-order evaluations on the 4n-point domain from the four coset tables of a column:
+// out[4k + r] = plane_r[k].  Plane 0 is the column's own table (field elements, or raw u64 indices
+// converted with F::from), planes 1..3 are consecutive n-element blocks at `planes`.
+struct Interleave4Args {
+  const uint64_t* plane0[24];
+  uint32_t raw_index[24];      // 1 = plane 0 holds uint64_t indices
+  uint64_t* out[24];
+  const uint64_t* planes;      // column b: planes + b * 3n elements
+  // Output layout: point i lands in chunk i / chunk at offset i % chunk; consecutive chunks of one
+  // column are chunk_stride elements apart, and each chunk is followed by copies of the first
+  // `halo` points of the next chunk (cyclically).  chunk = 4n, halo = 0 is the plain vector.
+  uint64_t chunk, chunk_stride, halo;
+};
+
+__global__ __launch_bounds__(EW_THREADS) void interleave4_kernel(Interleave4Args a, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * EW_THREADS + threadIdx.x;
+  if (i >= 4 * n) return;
+  const int b = blockIdx.y;
+  const uint64_t k = i >> 2;
+  const int r = (int)(i & 3);
+  Fe v;
+  if (r) v = fe_load(a.planes + ((uint64_t)b * 3 + (r - 1)) * n * 4, k);
+  else v = a.raw_index[b] ? fe_from_u64(a.plane0[b][k]) : fe_load(a.plane0[b], k);
+  const uint64_t c = i / a.chunk, j = i - c * a.chunk;
+  fe_store(a.out[b], c * a.chunk_stride + j, v);
+  if (j < a.halo) {
+    const uint64_t chunks = 4 * n / a.chunk, prev = c ? c - 1 : chunks - 1;
+    fe_store(a.out[b], prev * a.chunk_stride + a.chunk + j, v);
+  }
+}
+
 // out[i] = F::from(idx[i])  (src/permutation_polynomial.rs:281)
 __global__ __launch_bounds__(EW_THREADS) void index_to_field_kernel(const uint64_t* idx, uint64_t n, uint64_t* out) {
   const uint64_t i = (uint64_t)blockIdx.x * EW_THREADS + threadIdx.x;

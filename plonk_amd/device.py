@@ -111,6 +111,25 @@ class DeviceProver:
         self.ctx.check(self.lib.plk_dev_sigma_table(self.ctx.handle, self._stream(), _table(node_ids), n, _table(out)))
         return out
 
+    def extend4(self, cols: Sequence[torch.Tensor], n: int, kinds: Optional[Sequence[int]] = None) -> List[torch.Tensor]:
+        """Interpolate each column (n rows) and evaluate it on the 4n-point domain, natural order."""
+        out = [self.empty(4 * n) for _ in cols]
+        karr = (C.c_uint32 * len(cols))(*kinds) if kinds is not None else None
+        self.ctx.check(self.lib.plk_dev_extend4(self.ctx.handle, self._stream(), _table(cols), karr, len(cols), n, None, _table(out),
+                                                0, 0, 0))
+        return out
+
+    def extend4_chunked(self, cols: Sequence[torch.Tensor], n: int, kinds, parts: int, slots: int, halo: int) -> torch.Tensor:
+        """The same evaluations laid out for an exchange between `parts` ranks: returns a
+        `(parts, slots, 4n / parts + halo, 4)` tensor whose [h, b] holds column b's points of range h followed by the
+        first `halo` points of the next range (cyclically); rows b >= len(cols) stay zero."""
+        chunk = 4 * n // parts
+        out = torch.zeros((parts, slots, chunk + halo, 4), dtype=torch.int64, device=self.device)
+        karr = (C.c_uint32 * len(cols))(*kinds) if kinds is not None else None
+        self.ctx.check(self.lib.plk_dev_extend4(self.ctx.handle, self._stream(), _table(cols), karr, len(cols), n, None,
+                                                _table([out[0, b] for b in range(len(cols))]), chunk, slots * (chunk + halo), halo))
+        return out
+
     def grand_product(self, dc: DeviceCircuit, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         z = self.empty(dc.n + 1) if out is None else out
         self.ctx.check(self.lib.plk_dev_grand_product(self.ctx.handle, self._stream(), _table(dc.wires), _table(dc.sigma), dc.n,

@@ -171,16 +171,20 @@ def round23_poly_sharded(engine, wires: Sequence[torch.Tensor], selectors: Seque
     mine = [present[i] for i in assign_columns(len(present), group)]
     per_rank = (len(present) + G - 1) // G
 
-    # my columns: interpolate, extend to N points
-    evals = torch.zeros((per_rank, N + z_shift, 4), dtype=torch.int64, device=z.device)
-    if mine:
-        coefs = engine.ntt_batch([cols[i].contiguous() for i in mine], n, inverse=True, kinds=[kinds[i] for i in mine])
-        ext = engine.ntt_batch(coefs, N)
-        for slot, e in enumerate(ext):
-            evals[slot, :N] = e
-            evals[slot, N:] = e[:z_shift]                                # wrap-around halo for z[(i + shift) mod N]
-    # exchange: slot-major, all points  ->  every rank's slots, my points (+ halo)
-    send = torch.stack([evals[:, h * chunk:(h + 1) * chunk + z_shift] for h in range(G)]).contiguous()   # [G][slot][chunk+halo]
+    # my columns: interpolate, extend to N points, laid out [destination rank][slot][its points + halo of z_shift points]
+    my_cols, my_kinds = [cols[i].contiguous() for i in mine], [kinds[i] for i in mine]
+    if N == 4 * n and n >= 4 and z_shift <= chunk and hasattr(engine, "extend4_chunked"):
+        # three n-point coset transforms per column, written straight into the exchange layout
+        send = engine.extend4_chunked(my_cols, n, my_kinds, G, per_rank, z_shift)
+    else:
+        evals = torch.zeros((per_rank, N + z_shift, 4), dtype=torch.int64, device=z.device)
+        if mine:
+            ext = engine.ntt_batch(engine.ntt_batch(my_cols, n, inverse=True, kinds=my_kinds), N)
+            for slot, e in enumerate(ext):
+                evals[slot, :N] = e
+                evals[slot, N:] = e[:z_shift]                            # wrap-around halo for z[(i + shift) mod N]
+        send = torch.stack([evals[:, h * chunk:(h + 1) * chunk + z_shift] for h in range(G)]).contiguous()
+    # exchange: my slots, every rank's points  ->  every rank's slots, my points (+ halo)
     recv = _all_to_all(send, group)                                      # [source rank][slot][chunk+halo]
     local = {}
     for src in range(G):

@@ -141,3 +141,20 @@ def test_linearity_of_the_transform(ctx):
     got = synth.mont_to_ints(fs[:128])
     want = [(x + y) % synth.P_INT for x, y in zip(synth.mont_to_ints(fa[:128]), synth.mont_to_ints(fb[:128]))]
     assert got == want
+
+
+@pytest.mark.parametrize("log_n", [2, 3, 6, 11, 12, 17])
+def test_extend4_equals_padded_transform(prover, log_n):
+    """plk_dev_extend4 (three coset transforms + the input column) against interpolation followed by the
+    zero-padded 4n-point transform, for field columns and for an index column."""
+    from plonk_amd.device import to_device, to_host
+    n = 1 << log_n
+    c = synth.make_circuit(n, circuit_id=log_n)
+    cols = [to_device(c.table.input1, prover.device), to_device(c.table.output, prover.device), to_device(c.perm.sigma2, prover.device)]
+    kinds = [_lib.INPUT_FIELD, _lib.INPUT_FIELD, _lib.INPUT_U64]
+    got = prover.extend4(cols, n, kinds=kinds)
+    want = prover.ntt_batch(prover.ntt_batch(cols, n, inverse=True, kinds=kinds), 4 * n)
+    for g, w in zip(got, want):
+        assert np.array_equal(to_host(g), to_host(w))
+    ref = co.ntt(co.intt(c.table.input1, n), 4 * n)
+    assert np.array_equal(to_host(got[0]), ref)
