@@ -1,0 +1,235 @@
+// Parity tests of the C++ host mirror (include/plonk_hip.hpp) on a GPU, written the way tests of the
+// reference's own functions would read: build a table, call the function under its reference name,
+// compare with the CPU oracle (oracle/plonk_oracle.c, the checker) bit for bit.
+// Built by `make -C tests/cpp`; run by tests/test_gpu_cpp_mirror.py.  Exit code = number of failures.
+#include <cinttypes>
+#include <cstdio>
+#include <cstring>
+
+#include "plonk_hip.hpp"
+
+using namespace plonk_hip;
+using u64 = uint64_t;
+
+extern "C" {
+void orc_to_mont(const u64* in, size_t n, u64* out);
+int orc_intt(const u64* evals, size_t evals_len, size_t domain_size, u64* out);
+int orc_gate_polys(const u64* const wires[4], const u64* const sel[9], size_t n, size_t domain_size, u64* const wires_out[4],
+                   u64* const sel_out[9]);
+int orc_gate_constraints(const u64* const wire_coeffs[4], const u64* const sel_coeffs[9], size_t n_coeffs, size_t N, u64* out);
+int orc_grand_product(const u64* const wires[4], const u64* const sigma[4], size_t n, const u64* beta, const u64* gamma, u64* z_out,
+                      int64_t* bad_row);
+int orc_perm_polys(const u64* const wires[4], const u64* const sigma[4], size_t n, size_t domain_size, const u64* beta, const u64* gamma,
+                   u64* const sigma_coeffs_out[4], u64* z_coeffs_out, u64* z_last, int64_t* bad_row);
+int orc_perm_constraints(const u64* z_coeffs, const u64* const sigma_coeffs[4], const u64* const wire_coeffs[4], size_t n_coeffs, size_t N,
+                         const u64* beta, const u64* gamma, size_t z_shift, u64* out);
+int orc_round23(const u64* const wires[4], const u64* const sel[9], const u64* const sigma[4], size_t n, size_t N, const u64* beta,
+                const u64* gamma, size_t z_shift, u64* z_out, u64* gate_out, u64* perm_out, int64_t* bad_row);
+int orc_sigma_table(const u64* const node_ids[4], size_t n, u64* const sigma_out[4]);
+int orc_gate_table_fill(const uint8_t* row_ops, const u64* const node_ids[4], size_t n, const u64* node_values, size_t n_values,
+                        const u64* default_val, u64* const wires_out[4], u64* const sel_out[9]);
+}
+
+static int failures = 0;
+#define CHECK(cond)                                                                  \
+  do {                                                                               \
+    if (!(cond)) { ++failures; std::printf("  FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); } \
+  } while (0)
+
+// ---- seeded inputs (splitmix64; any residue below the modulus is a valid element) -------------------
+static u64 sm_state;
+static u64 splitmix() {
+  u64 z = (sm_state += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+static Fr random_fr() { return Fr{splitmix(), splitmix(), splitmix(), splitmix() >> 2}; }   // top limb below 2^62 < modulus' top limb
+static Fr from_int(u64 x) { Fr c{x, 0, 0, 0}, m; orc_to_mont(c.data(), 1, m.data()); return m; }
+static std::vector<Fr> random_column(size_t n) { std::vector<Fr> v(n); for (auto& e : v) e = random_fr(); return v; }
+
+struct Circuit { GateEvaluationTable table; PermutationTable perm; Fr beta, gamma; };
+static const ASTKind ALL_KINDS[9] = {ASTKind::Int, ASTKind::Bool, ASTKind::Add, ASTKind::Sub, ASTKind::Mult,
+                                     ASTKind::Div, ASTKind::Eq, ASTKind::Not, ASTKind::If};
+
+static Circuit make_circuit(size_t n, u64 seed, int n_kinds = 9) {
+  sm_state = seed;
+  Circuit c;
+  c.table.input1 = random_column(n); c.table.input2 = random_column(n);
+  c.table.input3 = random_column(n); c.table.output = random_column(n);
+  const Fr one = from_int(1), zero{0, 0, 0, 0};
+  for (int k = 0; k < n_kinds; ++k) c.table.selectors[ALL_KINDS[k]].assign(n, zero);
+  for (size_t j = 0; j < n; ++j) c.table.selectors[ALL_KINDS[splitmix() % n_kinds]][j] = one;
+  std::vector<u64>* sg[4] = {&c.perm.sigma1, &c.perm.sigma2, &c.perm.sigma3, &c.perm.sigma_output};
+  for (auto* s : sg) {                       // Fisher-Yates
+    s->resize(n);
+    for (size_t j = 0; j < n; ++j) (*s)[j] = j;
+    for (size_t j = n; j > 1; --j) std::swap((*s)[j - 1], (*s)[splitmix() % j]);
+  }
+  c.beta = random_fr(); c.gamma = random_fr();
+  return c;
+}
+
+struct Ptrs {           // the oracle takes the same pointer tables as the C ABI
+  const u64* wires[4]; const u64* sel[9]; const u64* sigma[4];
+  explicit Ptrs(const Circuit& c) {
+    const std::vector<Fr>* w[4] = {&c.table.input1, &c.table.input2, &c.table.input3, &c.table.output};
+    const std::vector<u64>* s[4] = {&c.perm.sigma1, &c.perm.sigma2, &c.perm.sigma3, &c.perm.sigma_output};
+    for (int k = 0; k < 4; ++k) { wires[k] = (*w[k])[0].data(); sigma[k] = s[k]->data(); }
+    for (int k = 0; k < 9; ++k) sel[k] = nullptr;
+    for (const auto& kv : c.table.selectors) sel[(int)kv.first] = kv.second[0].data();
+  }
+};
+
+static std::vector<Fr> padded(const DensePolynomial& p, size_t n) { auto v = p.coeffs; v.resize(n, Fr{0, 0, 0, 0}); return v; }
+
+// ---- tests ------------------------------------------------------------------------------------------
+
+static void test_evaluations_to_dense_polynomial() {
+  std::printf("test_evaluations_to_dense_polynomial\n");
+  for (size_t n : {size_t(1), size_t(2), size_t(8), size_t(1) << 12}) {
+    sm_state = 17 + n;
+    const std::vector<Fr> evals = random_column(n);
+    const DensePolynomial p = evaluations_to_dense_polynomial(evals, GeneralEvaluationDomain(n));
+    std::vector<Fr> want(n);
+    CHECK(orc_intt(evals[0].data(), n, n, want[0].data()) == 0);
+    CHECK(padded(p, n) == want);
+  }
+  // a constant table interpolates to a degree-0 polynomial: trailing zeros are dropped (src/polynomial_utils.rs:32)
+  const DensePolynomial c = evaluations_to_dense_polynomial(std::vector<Fr>(16, from_int(5)), GeneralEvaluationDomain(16));
+  CHECK(c.coeffs.size() == 1 && c.coeffs[0] == from_int(5) && c.degree() == 0);
+  // "Evaluation length must match the domain size" (src/polynomial_utils.rs:22-26)
+  bool threw = false;
+  try { evaluations_to_dense_polynomial(std::vector<Fr>(7, from_int(1)), GeneralEvaluationDomain(8)); } catch (const LengthMismatch&) { threw = true; }
+  CHECK(threw);
+  threw = false;
+  try { build_and_convert(GeneralEvaluationDomain(8), [] { return std::vector<Fr>(9, Fr{1, 0, 0, 0}); }); } catch (const LengthMismatch&) { threw = true; }
+  CHECK(threw);
+  const DensePolynomial b = build_and_convert(GeneralEvaluationDomain(4), [] { return std::vector<Fr>(4, Fr{0, 0, 0, 0}); });
+  CHECK(b.coeffs.empty() && b.degree() == -1);
+}
+
+static void test_round_2_and_3_function_by_function(size_t n, size_t N, int n_kinds) {
+  std::printf("test_round_2_and_3_function_by_function n=%zu N=%zu kinds=%d\n", n, N, n_kinds);
+  const Circuit c = make_circuit(n, 1000 + n + N + n_kinds, n_kinds);
+  const Ptrs p(c);
+  const GeneralEvaluationDomain dn(n), dN(N);
+
+  const GatePolynomials gp = gate_evaluation_table_to_gate_polynomial(c.table, dn);
+  std::vector<Fr> w_ref[4], s_ref[9];
+  u64 *w_out[4], *s_out[9];
+  for (int k = 0; k < 4; ++k) { w_ref[k].resize(n); w_out[k] = w_ref[k][0].data(); }
+  for (int k = 0; k < 9; ++k) { s_out[k] = nullptr; if (p.sel[k]) { s_ref[k].resize(n); s_out[k] = s_ref[k][0].data(); } }
+  CHECK(orc_gate_polys(p.wires, p.sel, n, n, w_out, s_out) == 0);
+  CHECK(padded(gp.input1, n) == w_ref[0] && padded(gp.input2, n) == w_ref[1] && padded(gp.input3, n) == w_ref[2] && padded(gp.output, n) == w_ref[3]);
+  for (const auto& kv : gp.selectors) CHECK(padded(kv.second, n) == s_ref[(int)kv.first]);
+
+  const std::vector<Fr> z = build_grand_product_evaluation_polynomial(c.perm, c.table, c.beta, c.gamma);
+  std::vector<Fr> z_ref(n + 1);
+  int64_t bad = -1;
+  CHECK(orc_grand_product(p.wires, p.sigma, n, c.beta.data(), c.gamma.data(), z_ref[0].data(), &bad) == 0);
+  CHECK(z.size() == n + 1 && z == z_ref);
+
+  const PermutationPolynomials pp = build_permutation_polynomials(c.perm, c.table, c.beta, c.gamma, dn);
+  std::vector<Fr> sc_ref[4], zc_ref(n);
+  u64* sc_out[4];
+  Fr z_last_ref;
+  for (int k = 0; k < 4; ++k) { sc_ref[k].resize(n); sc_out[k] = sc_ref[k][0].data(); }
+  CHECK(orc_perm_polys(p.wires, p.sigma, n, n, c.beta.data(), c.gamma.data(), sc_out, zc_ref[0].data(), z_last_ref.data(), &bad) == 0);
+  CHECK(padded(pp.z, n) == zc_ref && pp.z_last && *pp.z_last == z_last_ref && *pp.z_last == z[n]);
+  CHECK(padded(pp.sigma1, n) == sc_ref[0] && padded(pp.sigma_output, n) == sc_ref[3]);
+
+  const std::vector<Fr> g = build_gate_constraint_evaluation_polynomial(gp, dN);
+  const u64* wc[4] = {w_ref[0][0].data(), w_ref[1][0].data(), w_ref[2][0].data(), w_ref[3][0].data()};
+  const u64* scs[9];
+  for (int k = 0; k < 9; ++k) scs[k] = p.sel[k] ? s_ref[k][0].data() : nullptr;
+  std::vector<Fr> g_ref(N), e_ref(N);
+  CHECK(orc_gate_constraints(wc, scs, n, N, g_ref[0].data()) == 0);
+  CHECK(g == g_ref);
+
+  const std::vector<Fr> e = build_permutation_constraint_evaluation_polynomial(pp, gp, c.beta, c.gamma, dN);
+  const u64* sgc[4] = {sc_ref[0][0].data(), sc_ref[1][0].data(), sc_ref[2][0].data(), sc_ref[3][0].data()};
+  CHECK(orc_perm_constraints(zc_ref[0].data(), sgc, wc, n, N, c.beta.data(), c.gamma.data(), 1, e_ref[0].data()) == 0);
+  CHECK(e == e_ref);
+
+  const Round23 r = prove_round23(c.table, c.perm, c.beta, c.gamma, dn, dN);
+  CHECK(r.z == z_ref && r.gate_constraints == g_ref && r.permutation_constraints == e_ref);
+}
+
+static void test_panics_become_exceptions() {
+  std::printf("test_panics_become_exceptions\n");
+  Circuit c = make_circuit(64, 77);
+  // sigma index past the end: slice index panic of src/permutation_polynomial.rs:235-238, reported with its row
+  c.perm.sigma3[41] = 64;
+  try { build_grand_product_evaluation_polynomial(c.perm, c.table, c.beta, c.gamma); CHECK(!"no exception"); }
+  catch (const SigmaOutOfRange& e) { CHECK(e.row == 41); }
+  c.perm.sigma3[41] = 0;
+  // zero denominator at row 5: v + beta * 5 + gamma = 0 for the first wire (`inverse().unwrap()`, :258).
+  // With beta = 0 the term is v + gamma: take gamma = -v by setting v = 0 and gamma = 0.
+  c.beta = Fr{0, 0, 0, 0}; c.gamma = Fr{0, 0, 0, 0}; c.table.input1[5] = Fr{0, 0, 0, 0};
+  try { build_grand_product_evaluation_polynomial(c.perm, c.table, c.beta, c.gamma); CHECK(!"no exception"); }
+  catch (const ZeroDenominator& e) { CHECK(e.row == 5); }
+  // the context stays usable after a failure
+  const Circuit ok = make_circuit(64, 78);
+  CHECK(build_grand_product_evaluation_polynomial(ok.perm, ok.table, ok.beta, ok.gamma).size() == 65);
+  // not a power of two
+  bool threw = false;
+  try { evaluations_to_dense_polynomial(std::vector<Fr>(12, Fr{0, 0, 0, 0}), GeneralEvaluationDomain(12)); } catch (const Error& e) { threw = e.code == PLK_ERR_NOT_POW2; }
+  CHECK(threw);
+}
+
+static void test_tables_from_a_trace() {
+  std::printf("test_tables_from_a_trace\n");
+  // Add(Int 40, Int 2) (src/ast.rs:473-477): one double-input row; nodes: 0 = the sum, 1 = 40, 2 = 2
+  FlatTrace ex;
+  ex.row_ops = {PLK_ROW_OP((int)ASTKind::Add, 2)};
+  ex.node_ids[0] = {1}; ex.node_ids[1] = {2}; ex.node_ids[2] = {PLK_NO_WIRE}; ex.node_ids[3] = {0};
+  ex.node_values = {from_int(42), from_int(40), from_int(2)};
+  const GateEvaluationTable t = build_gate_evaluation_table(ex, from_int(0));
+  CHECK(t.input1[0] == from_int(40) && t.input2[0] == from_int(2) && t.input3[0] == from_int(0) && t.output[0] == from_int(42));
+  CHECK(t.selectors.size() == 1 && t.selectors.at(ASTKind::Add)[0] == from_int(1));
+  const PermutationTable s = build_permutation_table(ex);
+  CHECK(s.sigma1[0] == 0 && s.sigma2[0] == 0 && s.sigma3[0] == 0 && s.sigma_output[0] == 0);
+
+  // a seeded trace of 5000 rows: every row's output is a fresh node, inputs reuse earlier nodes
+  const size_t n = 5000, leaves = 700;
+  sm_state = 4242;
+  FlatTrace tr;
+  tr.row_ops.resize(n);
+  for (auto& col : tr.node_ids) col.assign(n, PLK_NO_WIRE);
+  for (size_t j = 0; j < n; ++j) {
+    const int inputs = 1 + (int)(splitmix() % 3);
+    const int kind = inputs == 1 ? (int)ASTKind::Not : inputs == 3 ? (int)ASTKind::If : 2 + (int)(splitmix() % 5);
+    tr.row_ops[j] = PLK_ROW_OP(kind, inputs);
+    for (int w = 0; w < inputs; ++w) tr.node_ids[w][j] = splitmix() % (leaves + j);
+    tr.node_ids[3][j] = leaves + j;
+  }
+  tr.node_values = random_column(leaves + n - 100);          // the newest 100 nodes have no value: default applies
+  const Fr dv = from_int(9);
+  const GateEvaluationTable gt = build_gate_evaluation_table(tr, dv);
+  const PermutationTable pt = build_permutation_table(tr);
+  const u64* ids[4] = {tr.node_ids[0].data(), tr.node_ids[1].data(), tr.node_ids[2].data(), tr.node_ids[3].data()};
+  std::vector<Fr> w_ref[4], s_ref[9];
+  std::vector<u64> sg_ref[4];
+  u64 *w_out[4], *s_out[9], *sg_out[4];
+  for (int k = 0; k < 4; ++k) { w_ref[k].resize(n); w_out[k] = w_ref[k][0].data(); sg_ref[k].resize(n); sg_out[k] = sg_ref[k].data(); }
+  for (int k = 0; k < 9; ++k) { s_ref[k].resize(n); s_out[k] = s_ref[k][0].data(); }
+  CHECK(orc_gate_table_fill(tr.row_ops.data(), ids, n, tr.node_values[0].data(), tr.node_values.size(), dv.data(), w_out, s_out) == 0);
+  CHECK(orc_sigma_table(ids, n, sg_out) == 0);
+  CHECK(gt.input1 == w_ref[0] && gt.input2 == w_ref[1] && gt.input3 == w_ref[2] && gt.output == w_ref[3]);
+  for (const auto& kv : gt.selectors) CHECK(kv.second == s_ref[(int)kv.first]);
+  CHECK(gt.selectors.size() == 7);                            // Add..If occur; Int and Bool have no rows
+  CHECK(pt.sigma1 == sg_ref[0] && pt.sigma2 == sg_ref[1] && pt.sigma3 == sg_ref[2] && pt.sigma_output == sg_ref[3]);
+}
+
+int main() {
+  test_evaluations_to_dense_polynomial();
+  test_round_2_and_3_function_by_function(4, 16, 9);
+  test_round_2_and_3_function_by_function(1 << 10, 1 << 10, 9);     // "check" use: N = n
+  test_round_2_and_3_function_by_function(1 << 10, 1 << 12, 9);
+  test_round_2_and_3_function_by_function(1 << 13, 1 << 15, 4);     // a subset of the selector kinds
+  test_panics_become_exceptions();
+  test_tables_from_a_trace();
+  std::printf("%d failure(s)\n", failures);
+  return failures;
+}
