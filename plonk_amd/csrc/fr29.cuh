@@ -121,11 +121,15 @@ __host__ __device__ __forceinline__ Fe fe_reduce_f9(F9 a) {
 // ---- arithmetic --------------------------------------------------------------------------
 
 // a * b * 2^-261 mod p, product scanning with the reduction interleaved column by column.
-// p = 1 mod 2^29 for every field with two-adicity >= 29, hence m_k = -t_k mod 2^29 and the
-// p[0] term is the bare addition of m_k.
+// p = 1 mod 2^29 for every field with two-adicity >= 29, hence m_k = -t_k mod 2^29 and the p[0]
+// term is the bare addition of m_k.  That addition is never made: a reduced column t_k + m_k is a
+// multiple of 2^29, so its carry is (t_k + 2^29 - 1) >> 29 whatever m_k is.  The accumulator
+// therefore carries the bias B = t + (2^29 - 1) through the nine reduced columns; then
+// m_k = -(B - (2^29 - 1)) = ~B (mod 2^29) and the carry is B >> 29: two operations per column
+// instead of four.
 __device__ __forceinline__ F9 mont29(const F9& a, const F9& b) {
   static_assert(f9c::kp_limb29(1, 0) == 1, "modulus must be 1 mod 2^29");
-  uint64_t acc = 0;
+  uint64_t acc = M29;
   uint32_t m[9];
   F9 r;
 #pragma unroll
@@ -134,9 +138,8 @@ __device__ __forceinline__ F9 mont29(const F9& a, const F9& b) {
     for (int i = 0; i <= k; ++i) acc += (uint64_t)a.l[i] * b.l[k - i];
 #pragma unroll
     for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * f9c::kp_limb29(1, k - i);
-    m[k] = (0u - (uint32_t)acc) & M29;
-    acc += m[k];
-    acc >>= 29;
+    m[k] = ~(uint32_t)acc & M29;
+    acc = (acc >> 29) + (k < 8 ? (uint64_t)M29 : 0);
   }
 #pragma unroll
   for (int k = 9; k < 17; ++k) {
@@ -156,7 +159,7 @@ __device__ __forceinline__ F9 mont29(const F9& a, const F9& b) {
 // 64-bit adds); interleaving the two chains keeps dependent multiply-adds two issues apart.
 #define PLK_PIN(x) asm volatile("" : "+v"(x))
 __device__ __forceinline__ void mont29_x2(const F9& a1, const F9& b1, const F9& a2, const F9& b2, F9& r1, F9& r2) {
-  uint64_t acc1 = 0, acc2 = 0;
+  uint64_t acc1 = M29, acc2 = M29;   // biased accumulators, as in mont29
   uint32_t m1[9], m2[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) {
@@ -170,10 +173,8 @@ __device__ __forceinline__ void mont29_x2(const F9& a1, const F9& b1, const F9& 
       acc1 += (uint64_t)m1[i] * f9c::kp_limb29(1, k - i); acc2 += (uint64_t)m2[i] * f9c::kp_limb29(1, k - i);
       PLK_PIN(acc1); PLK_PIN(acc2);
     }
-    m1[k] = (0u - (uint32_t)acc1) & M29; m2[k] = (0u - (uint32_t)acc2) & M29;
-    acc1 += m1[k]; acc2 += m2[k];
-    PLK_PIN(acc1); PLK_PIN(acc2);
-    acc1 >>= 29; acc2 >>= 29;
+    m1[k] = ~(uint32_t)acc1 & M29; m2[k] = ~(uint32_t)acc2 & M29;
+    acc1 = (acc1 >> 29) + (k < 8 ? (uint64_t)M29 : 0); acc2 = (acc2 >> 29) + (k < 8 ? (uint64_t)M29 : 0);
   }
 #pragma unroll
   for (int k = 9; k < 17; ++k) {
