@@ -143,9 +143,37 @@ __device__ __forceinline__ void tile_dit(const Tile& t, int log_r, int log_c, co
   }
   int first = 0;
   if (log_r >= 2) { tile_first_radix4(t, log_r, log_c, master, quarter); first = 2; }
+  // Two stages at a time in registers: a thread holds rows i0, i0 + h, i0 + 2h, i0 + 3h of one column,
+  // runs the stage of half-size h on (0,1), (2,3) and the stage of half-size 2h on (0,2), (1,3), and
+  // writes the four rows back once - half the LDS traffic, address arithmetic and barriers of two
+  // separate stages, the same four products (two interleaved pairs).
+  const int groups = log_r >= 2 ? 1 << (log_r + log_c - 2) : 0;
+  for (; first + 1 < log_r; first += 2) {
+    const int lh = first, h = 1 << lh;
+    for (int g = threadIdx.x; g < groups; g += NTT_THREADS) {
+      const int c = g & ((1 << log_c) - 1), q = g >> log_c;
+      const int j = q & (h - 1);
+      const int i0 = ((q >> lh) << (lh + 2)) + j;
+      const int e0 = (i0 << log_c) + c, step = h << log_c;
+      const F9 x0 = t.get(e0), x1 = t.get(e0 + step), x2 = t.get(e0 + 2 * step), x3 = t.get(e0 + 3 * step);
+      auto tw = [&](int idx) { return tw_lds ? ltw.get(idx) : f9_load_tw(master, (size_t)idx << (NTT_MASTER_LOG - log_r)); };
+      const F9 w1 = tw(j << (log_r - 1 - lh));                                   // omega_{2h}^j
+      F9 t1, t3;
+      mont29_x2(x1, w1, x3, w1, t1, t3);
+      const F9 a0 = f9_add(x0, t1), a1 = f9_sub_q2(x0, t1), a2 = f9_add(x2, t3), a3 = f9_sub_q2(x2, t3);
+      const F9 w2 = tw(j << (log_r - 2 - lh)), w3 = tw((j + h) << (log_r - 2 - lh));   // omega_{4h}^j, omega_{4h}^(j+h)
+      F9 s2, s3;
+      mont29_x2(a2, w2, a3, w3, s2, s3);
+      F9 y0 = f9_add(a0, s2), y2 = f9_sub_q2(a0, s2), y1 = f9_add(a1, s3), y3 = f9_sub_q2(a1, s3);
+      f9_normalize(y0); f9_normalize(y1); f9_normalize(y2); f9_normalize(y3);
+      t.put(e0, y0); t.put(e0 + step, y1); t.put(e0 + 2 * step, y2); t.put(e0 + 3 * step, y3);
+    }
+    __syncthreads();
+  }
+  const int fused_from = log_r >= 2 ? 2 : 0;   // parity of the renormalisation below counts from here
   for (int lh = first; lh < log_r; ++lh) {
     const int h = 1 << lh;
-    const bool renorm = ((lh - first) & 1) != 0;   // after every second stage
+    const bool renorm = ((lh - fused_from) & 1) != 0;   // after every second stage
     // two butterflies per thread and iteration, their products interleaved (mont29_x2)
     for (int b = threadIdx.x; b < total; b += 2 * NTT_THREADS) {
       const int bb[2] = {b, b + NTT_THREADS};
