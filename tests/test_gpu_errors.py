@@ -100,3 +100,64 @@ def test_empty_and_single_row(ctx):
     assert np.array_equal(z1, co.grand_product(c.table.wires(), c.perm.columns(), c.beta, c.gamma))
     # zero coefficients evaluate to zero
     assert not pa.evaluate_over_domain(empty, D(8), ctx=ctx).any()
+
+
+def test_bad_arguments_of_the_newer_entry_points(ctx, prover):
+    """null tables, ranges outside the circuit, a finish that does not match its local call, chunk layouts
+    that do not tile the domain: all PLK_ERR_ARG, and the context keeps working afterwards."""
+    import torch
+    from plonk_amd.device import to_device
+    lib, h = ctx.lib, ctx.handle
+    assert lib.plk_sigma_table(h, None, 4, None) == _lib.PLK_ERR_ARG
+    assert lib.plk_gate_table_fill(h, None, None, 4, None, 0, None, None, None) == _lib.PLK_ERR_ARG
+    n = 64
+    c = synth.make_circuit(n)
+    wires = [to_device(w, prover.device) for w in c.table.wires()]
+    sigma = [to_device(s, prover.device) for s in c.perm.columns()]
+    with pytest.raises(pa.PlonkError) as ei:                       # rows reach past the circuit
+        prover.grand_product_local(wires, sigma, n, 60, 8, c.beta, c.gamma)
+    assert ei.value.code == _lib.PLK_ERR_ARG
+    totals = prover.grand_product_local(wires, sigma, n, 0, 32, c.beta, c.gamma)
+    with pytest.raises(pa.PlonkError) as ei:                       # finish with other rows than the local call
+        prover.grand_product_finish(16, torch.stack([totals, totals]), 0)
+    assert ei.value.code == _lib.PLK_ERR_ARG
+    with pytest.raises(pa.PlonkError) as ei:                       # `mine` outside the range table
+        prover.grand_product_finish(32, torch.stack([totals, totals]), 2)
+    assert ei.value.code == _lib.PLK_ERR_ARG
+    with pytest.raises(pa.PlonkError) as ei:                       # 3 parts do not divide 4n points
+        prover.extend4_chunked(wires[:1], n, [_lib.INPUT_FIELD], 3, 1, 1)
+    assert ei.value.code == _lib.PLK_ERR_ARG
+    with pytest.raises(pa.PlonkError) as ei:                       # extension needs n >= 4
+        prover.extend4([wires[0][:2].contiguous()], 2)
+    assert ei.value.code == _lib.PLK_ERR_TWO_ADICITY
+    # a non-reduced default value is rejected
+    t = synth.make_trace(8)
+    bad = np.full((4,), 0xFFFFFFFFFFFFFFFF, dtype=np.uint64)
+    with pytest.raises(pa.PlonkError) as ei:
+        pa.build_gate_evaluation_table(t.ops, t.node_ids, t.node_values, bad, ctx=ctx)
+    assert ei.value.code == _lib.PLK_ERR_ARG
+    # still healthy
+    z = prover.grand_product_cols(wires, sigma, n, c.beta, c.gamma)
+    prover.status()
+    import c_oracle as co
+    from plonk_amd.device import to_host
+    assert np.array_equal(to_host(z), co.grand_product(c.table.wires(), c.perm.columns(), c.beta, c.gamma))
+
+
+def test_sigma_table_random_shapes(ctx):
+    """many small random shapes: row counts around the chunk and scan-tile sizes, id ranges from 1 to 2^64."""
+    import c_oracle as co
+    rng = np.random.default_rng(2024)
+    for trial in range(40):
+        n = int(rng.integers(1, 3000))
+        bits = int(rng.integers(1, 65))
+        pool = max(1, int(rng.integers(1, 4 * n)))
+        ids_pool = rng.integers(0, 2 ** 63, size=pool, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=pool, dtype=np.uint64)
+        ids_pool >>= np.uint64(64 - bits)
+        ids_pool[ids_pool == np.uint64(po.NO_WIRE)] = np.uint64(0)
+        cols = [ids_pool[rng.integers(0, pool, size=n)] for _ in range(4)]
+        for w in range(3):
+            cols[w][rng.random(n) < 0.3] = np.uint64(po.NO_WIRE)
+        got = pa.build_permutation_table(cols, ctx=ctx)
+        want = co.sigma_table(cols)
+        assert all(np.array_equal(g, w) for g, w in zip(got.columns(), want)), (trial, n, bits, pool)
