@@ -308,6 +308,9 @@ int launch_ntt(plk_ctx* ctx, hipStream_t s, const uint64_t* const* in, const uin
     a.prescale = prescale;
     if (p == 0) from_user(a.batch); else from_tmp(a.batch);
     to_tmp(a.batch);
+    // a pass after the first works in place: its tile must pass through LDS between loads and stores,
+    // which a radix below 8 would not do (the plans never produce one)
+    if (p > 0 && lr <= 2) return fail(ctx, PLK_ERR_ARG, "internal: in-place pass with a radix below 8");
     const uint64_t tiles = 1ull << (log_n - lr - a.log_c);
     if (tiles * slots > 0x7fffffffull) return fail(ctx, PLK_ERR_ARG, "transform batch too large for one launch");
     a.slots = (uint32_t)slots;

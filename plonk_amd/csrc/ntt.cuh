@@ -103,106 +103,121 @@ __device__ __forceinline__ F9 load_input(const uint64_t* in, uint64_t idx, bool 
   return v;
 }
 
-// The first two stages of the tile transform as one radix-4 step in registers: rows 4i..4i+3 of
-// the bit-reversed tile, one multiplication (by omega_4) per four elements, no LDS round trip in
-// between.  `quarter`: only row 4i is non-zero (an n -> 4n extension's first pass), so the four
-// outputs are copies of it.  Outputs normalised, value < 7.2 p.
-__device__ __forceinline__ void tile_first_radix4(const Tile& t, int log_r, int log_c, const uint32_t* master, bool quarter) {
-  const int groups = 1 << (log_r + log_c - 2);
-  const F9 w4 = f9_load_tw(master, (size_t)1 << (NTT_MASTER_LOG - 2));   // omega_4 (or its inverse)
-  for (int g = threadIdx.x; g < groups; g += NTT_THREADS) {
-    const int c = g & ((1 << log_c) - 1), i = g >> log_c;
-    const int e0 = ((4 * i) << log_c) + c, step = 1 << log_c;
-    const F9 a0 = t.get(e0);
-    if (quarter) {
-      t.put(e0 + step, a0); t.put(e0 + 2 * step, a0); t.put(e0 + 3 * step, a0);
-      continue;
-    }
-    const F9 a1 = t.get(e0 + step), a2 = t.get(e0 + 2 * step), a3 = t.get(e0 + 3 * step);
-    const F9 u0 = f9_add(a0, a1), u1 = f9_sub_q2(a0, a1), u2 = f9_add(a2, a3);
-    const F9 u3 = mont29(f9_sub_q2(a2, a3), w4);
-    F9 y0 = f9_add(u0, u2), y2 = f9_sub_q4(u0, u2), y1 = f9_add(u1, u3), y3 = f9_sub_q2(u1, u3);
-    f9_normalize(y0); f9_normalize(y1); f9_normalize(y2); f9_normalize(y3);
-    t.put(e0, y0); t.put(e0 + step, y1); t.put(e0 + 2 * step, y2); t.put(e0 + 3 * step, y3);
-  }
-  __syncthreads();
-}
-
-// In-LDS decimation-in-time transform of size 2^log_r along the row axis of a
-// [2^log_r][2^log_c] tile whose rows were stored in bit-reversed order; leaves natural order.
+// Decimation-in-time transform of size 2^log_r along the row axis of a [2^log_r][2^log_c] tile,
+// with both ends open: `load(r, c)` yields input row r (natural order) of column c as a normalised
+// value, `store(k, c, v)` takes output row k.  Values pass through LDS only between steps:
+//   * the first two stages are one radix-4 step on rows r0, r0 + R/2, r0 + R/4, r0 + 3R/4 taken
+//     straight from `load` (their only non-trivial twiddle is omega_4: one product per four
+//     elements; `quarter`: only rows below R/4 are non-zero - the first pass of an n -> 4n
+//     extension - so the four outputs are copies of the one input);
+//   * later stages go in pairs, as a radix-4 step in registers on rows i0, i0+h, i0+2h, i0+3h (half
+//     the LDS traffic, address arithmetic and barriers of two separate stages, the same four
+//     products, issued as two interleaved pairs); an odd stage left over runs two butterflies per thread;
+//   * the last step hands its results to `store` instead of writing them back.
 // Outputs are lazy: limbs < 1.3 * 2^31, value < (4 + 2 log_r) p.
-__device__ __forceinline__ void tile_dit(const Tile& t, int log_r, int log_c, const uint32_t* master, bool quarter) {
-  const int total = log_r >= 1 ? 1 << (log_r + log_c - 1) : 0;  // butterflies per stage
+template <class Load, class Store>
+__device__ __forceinline__ void tile_transform(const Tile& t, int log_r, int log_c, const uint32_t* master, bool quarter,
+                                               Load load, Store store) {
+  const int cmask = (1 << log_c) - 1;
+  if (log_r == 0) {
+    for (int c = threadIdx.x; c <= cmask; c += NTT_THREADS) store(0, c, load(0, c));
+    return;
+  }
+  if (log_r == 1) {
+    for (int c = threadIdx.x; c <= cmask; c += NTT_THREADS) {
+      const F9 x = load(0, c), y = load(1, c);
+      store(0, c, f9_add(x, y));
+      store(1, c, f9_sub_q2(x, y));
+    }
+    return;
+  }
   // the 2^(log_r - 1) twiddles of this radix, omega_R^j, copied next to the tile when they fit
+  // (first used after the barrier that ends the first step)
   const Tile ltw(reinterpret_cast<unsigned char*>(t.A) + (size_t)NTT_TILE * 36, 1 << NTT_LDS_TW_LOG);
-  const bool tw_lds = log_r >= 1 && log_r - 1 <= NTT_LDS_TW_LOG;
-  if (tw_lds) {
+  const bool tw_lds = log_r - 1 <= NTT_LDS_TW_LOG;
+  if (tw_lds && log_r > 2) {
     const int count = 1 << (log_r - 1);
     for (int j = threadIdx.x; j < count; j += NTT_THREADS)
       ltw.put(j, f9_load_tw(master, (size_t)j << (NTT_MASTER_LOG - log_r)));
   }
-  int first = 0;
-  if (log_r >= 2) { tile_first_radix4(t, log_r, log_c, master, quarter); first = 2; }
-  // Two stages at a time in registers: a thread holds rows i0, i0 + h, i0 + 2h, i0 + 3h of one column,
-  // runs the stage of half-size h on (0,1), (2,3) and the stage of half-size 2h on (0,2), (1,3), and
-  // writes the four rows back once - half the LDS traffic, address arithmetic and barriers of two
-  // separate stages, the same four products (two interleaved pairs).
-  const int groups = log_r >= 2 ? 1 << (log_r + log_c - 2) : 0;
-  for (; first + 1 < log_r; first += 2) {
-    const int lh = first, h = 1 << lh;
+  auto tw = [&](int idx) { return tw_lds ? ltw.get(idx) : f9_load_tw(master, (size_t)idx << (NTT_MASTER_LOG - log_r)); };
+  const int groups = 1 << (log_r + log_c - 2);
+  const int quarter_rows = 1 << (log_r - 2);
+
+  {  // first step
+    const bool last = log_r == 2;
+    const F9 w4 = f9_load_tw(master, (size_t)1 << (NTT_MASTER_LOG - 2));   // omega_4 (or its inverse)
     for (int g = threadIdx.x; g < groups; g += NTT_THREADS) {
-      const int c = g & ((1 << log_c) - 1), q = g >> log_c;
+      const int c = g & cmask, i = g >> log_c;
+      const int r0 = (int)bitrev((uint32_t)i, log_r - 2);
+      const F9 a0 = load(r0, c);
+      F9 y0, y1, y2, y3;
+      if (quarter) {
+        y0 = y1 = y2 = y3 = a0;
+      } else {
+        const F9 a1 = load(r0 + 2 * quarter_rows, c), a2 = load(r0 + quarter_rows, c), a3 = load(r0 + 3 * quarter_rows, c);
+        const F9 u0 = f9_add(a0, a1), u1 = f9_sub_q2(a0, a1), u2 = f9_add(a2, a3);
+        const F9 u3 = mont29(f9_sub_q2(a2, a3), w4);
+        y0 = f9_add(u0, u2); y2 = f9_sub_q4(u0, u2); y1 = f9_add(u1, u3); y3 = f9_sub_q2(u1, u3);
+        f9_normalize(y0); f9_normalize(y1); f9_normalize(y2); f9_normalize(y3);
+      }
+      if (last) { store(4 * i, c, y0); store(4 * i + 1, c, y1); store(4 * i + 2, c, y2); store(4 * i + 3, c, y3); }
+      else {
+        const int e0 = ((4 * i) << log_c) + c, step = 1 << log_c;
+        t.put(e0, y0); t.put(e0 + step, y1); t.put(e0 + 2 * step, y2); t.put(e0 + 3 * step, y3);
+      }
+    }
+    if (last) return;
+    __syncthreads();
+  }
+
+  int lh = 2;
+  for (; lh + 1 < log_r; lh += 2) {   // two stages per step
+    const int h = 1 << lh;
+    const bool last = lh + 2 == log_r;
+    for (int g = threadIdx.x; g < groups; g += NTT_THREADS) {
+      const int c = g & cmask, q = g >> log_c;
       const int j = q & (h - 1);
       const int i0 = ((q >> lh) << (lh + 2)) + j;
       const int e0 = (i0 << log_c) + c, step = h << log_c;
       const F9 x0 = t.get(e0), x1 = t.get(e0 + step), x2 = t.get(e0 + 2 * step), x3 = t.get(e0 + 3 * step);
-      auto tw = [&](int idx) { return tw_lds ? ltw.get(idx) : f9_load_tw(master, (size_t)idx << (NTT_MASTER_LOG - log_r)); };
-      const F9 w1 = tw(j << (log_r - 1 - lh));                                   // omega_{2h}^j
+      const F9 w1 = tw(j << (log_r - 1 - lh));                                          // omega_{2h}^j
       F9 t1, t3;
       mont29_x2(x1, w1, x3, w1, t1, t3);
       const F9 a0 = f9_add(x0, t1), a1 = f9_sub_q2(x0, t1), a2 = f9_add(x2, t3), a3 = f9_sub_q2(x2, t3);
-      const F9 w2 = tw(j << (log_r - 2 - lh)), w3 = tw((j + h) << (log_r - 2 - lh));   // omega_{4h}^j, omega_{4h}^(j+h)
+      const F9 w2 = tw(j << (log_r - 2 - lh)), w3 = tw((j + h) << (log_r - 2 - lh));     // omega_{4h}^j, omega_{4h}^(j+h)
       F9 s2, s3;
       mont29_x2(a2, w2, a3, w3, s2, s3);
       F9 y0 = f9_add(a0, s2), y2 = f9_sub_q2(a0, s2), y1 = f9_add(a1, s3), y3 = f9_sub_q2(a1, s3);
       f9_normalize(y0); f9_normalize(y1); f9_normalize(y2); f9_normalize(y3);
-      t.put(e0, y0); t.put(e0 + step, y1); t.put(e0 + 2 * step, y2); t.put(e0 + 3 * step, y3);
+      if (last) { store(i0, c, y0); store(i0 + h, c, y1); store(i0 + 2 * h, c, y2); store(i0 + 3 * h, c, y3); }
+      else { t.put(e0, y0); t.put(e0 + step, y1); t.put(e0 + 2 * step, y2); t.put(e0 + 3 * step, y3); }
     }
+    if (last) return;
     __syncthreads();
   }
-  const int fused_from = log_r >= 2 ? 2 : 0;   // parity of the renormalisation below counts from here
-  for (int lh = first; lh < log_r; ++lh) {
-    const int h = 1 << lh;
-    const bool renorm = ((lh - fused_from) & 1) != 0;   // after every second stage
-    // two butterflies per thread and iteration, their products interleaved (mont29_x2)
+
+  {  // one stage left (lh = log_r - 1): two butterflies per thread, their products interleaved
+    const int h = 1 << lh, total = 1 << (log_r + log_c - 1);
     for (int b = threadIdx.x; b < total; b += 2 * NTT_THREADS) {
       const int bb[2] = {b, b + NTT_THREADS};
       const bool second = bb[1] < total;
-      int e0[2], e1[2], jj[2];
+      int row[2], col[2], jj[2];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int bu = (u == 1 && !second) ? b : bb[u];
-        const int c = bu & ((1 << log_c) - 1);
+        col[u] = bu & cmask;
         const int q = bu >> log_c;
         jj[u] = q & (h - 1);
-        const int i0 = ((q >> lh) << (lh + 1)) + jj[u];
-        e0[u] = (i0 << log_c) + c; e1[u] = ((i0 + h) << log_c) + c;
+        row[u] = ((q >> lh) << (lh + 1)) + jj[u];
       }
-      const F9 xa = t.get(e0[0]), xb = t.get(e0[1]);
-      F9 ya = t.get(e1[0]), yb = t.get(e1[1]);
-      if (lh > 0) {
-        const F9 wa = tw_lds ? ltw.get(jj[0] << (log_r - 1 - lh)) : f9_load_tw(master, (size_t)jj[0] << (NTT_MASTER_LOG - 1 - lh));
-        const F9 wb = tw_lds ? ltw.get(jj[1] << (log_r - 1 - lh)) : f9_load_tw(master, (size_t)jj[1] << (NTT_MASTER_LOG - 1 - lh));
-        F9 ta, tb;
-        mont29_x2(ya, wa, yb, wb, ta, tb);
-        ya = ta; yb = tb;
-      }
-      F9 ua = f9_add(xa, ya), va = f9_sub_q2(xa, ya), ub = f9_add(xb, yb), vb = f9_sub_q2(xb, yb);
-      if (renorm) { f9_normalize(ua); f9_normalize(va); f9_normalize(ub); f9_normalize(vb); }
-      t.put(e0[0], ua); t.put(e1[0], va);
-      if (second) { t.put(e0[1], ub); t.put(e1[1], vb); }
+      const F9 xa = t.get((row[0] << log_c) + col[0]), xb = t.get((row[1] << log_c) + col[1]);
+      const F9 ya = t.get(((row[0] + h) << log_c) + col[0]), yb = t.get(((row[1] + h) << log_c) + col[1]);
+      F9 ta, tb;
+      mont29_x2(ya, tw(jj[0] << (log_r - 1 - lh)), yb, tw(jj[1] << (log_r - 1 - lh)), ta, tb);
+      store(row[0], col[0], f9_add(xa, ta)); store(row[0] + h, col[0], f9_sub_q2(xa, ta));
+      if (second) { store(row[1], col[1], f9_add(xb, tb)); store(row[1] + h, col[1], f9_sub_q2(xb, tb)); }
     }
-    __syncthreads();
   }
 }
 
@@ -259,29 +274,26 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const NttPassArgs
   const int elems = 1 << (log_r + log_c);
   const uint32_t kind = a.first ? a.batch.kind_of(poly) : (uint32_t)NTT_IN_FIELD;
 
-  for (int e = threadIdx.x; e < elems; e += NTT_THREADS) {
-    const int r = e >> log_c, c = e & ((1 << log_c) - 1);
-    const uint64_t idx = base + ((uint64_t)r << log_inner) + c;
-    F9 v = load_input(in, idx, !(a.first && idx >= a.n_in), kind, a.tab.from_u64);
-    if (a.first && a.cosets) v = mont29(v, f9_load_tw(a.prescale, ((uint64_t)(slot % a.cosets) << a.log_n) + idx));
-    tile.put((int)(bitrev((uint32_t)r, log_r) << log_c) + c, v);
-  }
-  __syncthreads();
-  tile_dit(tile, log_r, log_c, a.tab.master, a.first && log_r >= 2 && (a.n_in << 2) <= (1ull << a.log_n));
-
   // inter-pass twiddle omega_{N'}^(k * q), N' = 2^(log_r + log_inner), as a power of omega_N
   const int shift = a.log_n - (log_r + log_inner);
   const uint32_t* hi = a.use_scaled ? a.tab.tw_hi_scaled : a.tab.tw_hi;
   const uint32_t* full = a.tab.tw_full[a.pass];
-  for (int e = threadIdx.x; e < elems; e += NTT_THREADS) {
-    const int k = e >> log_c, c = e & ((1 << log_c) - 1);
-    const uint64_t q = q0 + c;
-    F9 v = tile.get(e);
-    const F9 tw = full ? f9_load_tw(full, ((uint64_t)k << log_inner) + q)
-                       : twiddle_two_level(hi, a.tab.tw_lo, a.tab.lo_bits, ((uint64_t)k * q) << shift);
-    v = mont29(v, tw);
-    fe_store(out, base + ((uint64_t)k << log_inner) + c, fe_pack_f9(v));
-  }
+  const int coset = a.cosets ? slot % a.cosets : 0;
+  (void)elems;
+  tile_transform(
+      tile, log_r, log_c, a.tab.master, a.first && log_r >= 2 && (a.n_in << 2) <= (1ull << a.log_n),
+      [&](int r, int c) {   // row r of the digit this pass transforms: a run of 2^log_c consecutive elements per row
+        const uint64_t idx = base + ((uint64_t)r << log_inner) + c;
+        F9 v = load_input(in, idx, !(a.first && idx >= a.n_in), kind, a.tab.from_u64);
+        if (a.first && a.cosets) v = mont29(v, f9_load_tw(a.prescale, ((uint64_t)coset << a.log_n) + idx));
+        return v;
+      },
+      [&](int k, int c, const F9& v) {
+        const uint64_t q = q0 + c;
+        const F9 tw = full ? f9_load_tw(full, ((uint64_t)k << log_inner) + q)
+                           : twiddle_two_level(hi, a.tab.tw_lo, a.tab.lo_bits, ((uint64_t)k * q) << shift);
+        fe_store(out, base + ((uint64_t)k << log_inner) + c, fe_pack_f9(mont29(v, tw)));
+      });
 }
 
 struct NttFinalArgs {
@@ -327,18 +339,16 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_final_kernel(const NttFinalAr
     tile.put((int)(bitrev((uint32_t)r, log_r) << log_c) + c, v);
   }
   __syncthreads();
-  tile_dit(tile, log_r, log_c, a.tab.master, a.first && log_r >= 2 && (a.n_in << 2) <= (1ull << a.log_n));
-
   const bool scaled = a.tab.scale != nullptr;
   F9 sc;
   if (scaled) sc = f9_load_tw(a.tab.scale, 0);
-  for (int e = threadIdx.x; e < elems; e += NTT_THREADS) {
-    const int k = e >> log_c, c = e & ((1 << log_c) - 1);
-    F9 v = tile.get(e);
-    if (scaled) v = mont29(v, sc);
-    const uint64_t dst = (k1_0 + c) + (k2 << a.log_r1) + ((uint64_t)k << (a.log_r1 + a.log_r2));
-    fe_store(out, dst, fe_reduce_f9(v));
-  }
+  tile_transform(
+      tile, log_r, log_c, a.tab.master, a.first && log_r >= 2 && (a.n_in << 2) <= (1ull << a.log_n),
+      [&](int r, int c) { return tile.get((int)(bitrev((uint32_t)r, log_r) << log_c) + c); },
+      [&](int k, int c, const F9& v) {
+        const uint64_t dst = (k1_0 + c) + (k2 << a.log_r1) + ((uint64_t)k << (a.log_r1 + a.log_r2));
+        fe_store(out, dst, fe_reduce_f9(scaled ? mont29(v, sc) : v));
+      });
 }
 
 // ---- table construction (device side, run once per plan)
