@@ -313,6 +313,9 @@ struct NttFinalArgs {
 };
 
 // Last pass: contiguous rows in, natural-order scatter out (never in place), canonical values.
+// Row o_c = (k1_0 + c) * R2 + k2 of the pass-major buffer feeds column c of the tile; a thread of the
+// first step reads its four elements of that row straight from memory (32-byte pieces; the row's
+// lines are shared by neighbouring waves of the workgroup through the vector cache).
 __global__ __launch_bounds__(NTT_THREADS) void ntt_final_kernel(const NttFinalArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const Tile tile(lds_raw);
@@ -324,27 +327,20 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_final_kernel(const NttFinalAr
   const int log_c = a.log_c, log_r = a.log_r;
   const uint64_t k2 = blockIdx.x & ((1u << a.log_r2) - 1);
   const uint64_t k1_0 = (uint64_t)(blockIdx.x >> a.log_r2) << log_c;
-  const int elems = 1 << (log_r + log_c);
   const uint32_t kind = a.first ? a.batch.kind_of(poly) : (uint32_t)NTT_IN_FIELD;
 
-  // tile[bitrev(r)][c] <- row o_c = (k1_0 + c) * R2 + k2, element r.  Lanes run along c first:
-  // a wave reads 64 / C consecutive elements (>= one 128-byte line) of each of the C rows, and
-  // its LDS stores fall on C consecutive slots of one tile row (conflict-free).
-  for (int e = threadIdx.x; e < elems; e += NTT_THREADS) {
-    const int c = e & ((1 << log_c) - 1), r = e >> log_c;
-    const uint64_t orow = ((k1_0 + c) << a.log_r2) + k2;
-    const uint64_t idx = (orow << log_r) + r;
-    F9 v = load_input(in, idx, !(a.first && idx >= a.n_in), kind, a.tab.from_u64);
-    if (a.first && a.cosets) v = mont29(v, f9_load_tw(a.prescale, ((uint64_t)(slot % a.cosets) << a.log_n) + idx));
-    tile.put((int)(bitrev((uint32_t)r, log_r) << log_c) + c, v);
-  }
-  __syncthreads();
   const bool scaled = a.tab.scale != nullptr;
   F9 sc;
   if (scaled) sc = f9_load_tw(a.tab.scale, 0);
   tile_transform(
       tile, log_r, log_c, a.tab.master, a.first && log_r >= 2 && (a.n_in << 2) <= (1ull << a.log_n),
-      [&](int r, int c) { return tile.get((int)(bitrev((uint32_t)r, log_r) << log_c) + c); },
+      [&](int r, int c) {
+        const uint64_t orow = ((k1_0 + c) << a.log_r2) + k2;
+        const uint64_t idx = (orow << log_r) + r;
+        F9 v = load_input(in, idx, !(a.first && idx >= a.n_in), kind, a.tab.from_u64);
+        if (a.first && a.cosets) v = mont29(v, f9_load_tw(a.prescale, ((uint64_t)(slot % a.cosets) << a.log_n) + idx));
+        return v;
+      },
       [&](int k, int c, const F9& v) {
         const uint64_t dst = (k1_0 + c) + (k2 << a.log_r1) + ((uint64_t)k << (a.log_r1 + a.log_r2));
         fe_store(out, dst, fe_reduce_f9(scaled ? mont29(v, sc) : v));
