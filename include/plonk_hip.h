@@ -159,6 +159,26 @@ int plk_gate_table_fill(plk_ctx* ctx, const uint8_t* row_ops, const uint64_t* co
                         const uint64_t* node_values, size_t n_values, const uint64_t default_val[4],
                         uint64_t* const wires_out[PLK_NUM_WIRES], uint64_t* const sel_out[PLK_NUM_SELECTORS]);
 
+/* ---- the step after the path: coset transforms and the quotient --------------------------- */
+
+/* The reference stops at the two numerator vectors (README.md:12-14 done, :15-17 next) and has no
+ * code for what follows; these entry points are ark-poly 0.3's coset transform pair and the textbook
+ * division by the vanishing polynomial, for the caller that goes on to the quotient polynomial.
+ *
+ * plk_coset_ntt: inverse == 0: EvaluationDomain::coset_fft - the n_in coefficients (zero-padded) are
+ * evaluated at shift * omega^i, i < domain_size; inverse != 0: coset_ifft - domain_size evaluations
+ * at those points back to domain_size coefficients (n_in must equal domain_size).  ark-poly 0.3
+ * fixes shift = F::multiplicative_generator() (7 for this field); here it is a parameter.
+ *
+ * plk_quotient: numerators[i], i < count <= 8, are evaluation vectors (N elements each) on the coset
+ * shift * <omega_N>; writes the N coefficients of (sum_i alpha^i numerators[i]) / Z_H with
+ * Z_H(x) = x^n - 1, N / n <= 16.  PLK_ERR_ZERO_DENOMINATOR if Z_H vanishes on the coset (e.g.
+ * shift = 1, the reference's own evaluation domain). */
+int plk_coset_ntt(plk_ctx* ctx, const uint64_t* in, size_t n_in, size_t domain_size, const uint64_t shift[4], int inverse,
+                  uint64_t* out);
+int plk_quotient(plk_ctx* ctx, const uint64_t* const* numerators, size_t count, const uint64_t alpha[4], size_t n, size_t N,
+                 const uint64_t shift[4], uint64_t* coeffs_out);
+
 /* ---- device entry points (same arithmetic, device pointers, asynchronous) ---------------- */
 
 /* `batch` transforms of size N in one set of launches.  in[b] holds n_in valid elements
@@ -195,6 +215,12 @@ int plk_dev_mul(plk_ctx* ctx, void* stream, const uint64_t* a, const uint64_t* b
  * No counterpart in the reference (ark-poly runs one shared-memory FFT). */
 int plk_dev_twiddle_block(plk_ctx* ctx, void* stream, size_t N, int inverse, int scale_by_inverse_n, size_t rows, size_t cols,
                           size_t row0, size_t col0, uint64_t* out);
+
+/* plk_coset_ntt for `batch` device columns, plk_quotient on device vectors (alpha, shift stay host pointers) */
+int plk_dev_coset_ntt(plk_ctx* ctx, void* stream, const uint64_t* const* in, size_t batch, size_t n_in, size_t N,
+                      const uint64_t shift[4], int inverse, uint64_t* const* out);
+int plk_dev_quotient(plk_ctx* ctx, void* stream, const uint64_t* const* numerators, size_t count, const uint64_t alpha[4],
+                     size_t n, size_t N, const uint64_t shift[4], uint64_t* coeffs_out);
 
 /* plk_gate_table_fill on device memory (default_val stays a host pointer) */
 int plk_dev_gate_table_fill(plk_ctx* ctx, void* stream, const uint8_t* row_ops, const uint64_t* const node_ids[PLK_NUM_WIRES],

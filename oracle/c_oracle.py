@@ -186,3 +186,19 @@ def gate_table_fill(ops, node_ids, node_values, default_val, kinds_present=AST_K
     if rc:
         raise OracleError(rc)
     return w_out, {k: s_out[i] for i, k in enumerate(AST_KINDS) if s_out[i] is not None}
+
+
+def coset_ntt(coeffs, N, shift):
+    coeffs = _c(coeffs); out = np.empty((N, 4), dtype=np.uint64)
+    _chk(lib().orc_coset_ntt(_p(coeffs), C.c_size_t(coeffs.shape[0]), C.c_size_t(N), _p(_c(shift)), _p(out))); return out
+
+
+def coset_intt(evals, shift):
+    evals = _c(evals); N = evals.shape[0]; out = np.empty((N, 4), dtype=np.uint64)
+    _chk(lib().orc_coset_intt(_p(evals), C.c_size_t(N), _p(_c(shift)), _p(out))); return out
+
+
+def quotient(numerators, alpha, n, shift):
+    nums = [_c(a) for a in numerators]; N = nums[0].shape[0]; out = np.empty((N, 4), dtype=np.uint64)
+    _chk(lib().orc_quotient(_tab(nums), C.c_size_t(len(nums)), _p(_c(alpha)), C.c_size_t(n), C.c_size_t(N), _p(_c(shift)), _p(out)))
+    return out

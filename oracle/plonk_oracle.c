@@ -379,6 +379,67 @@ int orc_gate_table_fill(const uint8_t* row_ops, const u64* const node_ids[4], si
   return 0;
 }
 
+/* ---- coset transforms and quotient completion ----
+ * ark-poly 0.3 `coset_fft` / `coset_ifft`: coefficient j times shift^j, then the plain transform (and
+ * back); the quotient is the textbook division by Z_H(x) = x^n - 1 on the coset shift * <omega_N>.
+ * The reference has no code for this step (README.md:15-17). */
+static void scale_by_powers(fe* v, size_t len, fe base) {
+  /* serial powers per chunk start, parallel over chunks */
+  long chunks = (long)((len + 4095) / 4096);
+#pragma omp parallel for schedule(static)
+  for (long c = 0; c < chunks; ++c) {
+    size_t lo = (size_t)c * 4096, hi = lo + 4096 < len ? lo + 4096 : len;
+    fe g = fe_pow_u64(base, (u64)lo);
+    for (size_t j = lo; j < hi; ++j) { v[j] = fe_mul(v[j], g); g = fe_mul(g, base); }
+  }
+}
+int orc_coset_ntt(const u64* coeffs, size_t n_coeffs, size_t N, const u64* shift_, u64* out) {
+  int log_n = log2_exact(N);
+  if (log_n < 0) return ORC_ERR_NOT_POW2;
+  if (log_n > TWO_ADICITY) return ORC_ERR_TWO_ADICITY;
+  if (n_coeffs > N) return ORC_ERR_LENGTH;
+  fe shift; memcpy(&shift, shift_, 32);
+  memcpy(out, coeffs, n_coeffs * 32);
+  memset(out + 4 * n_coeffs, 0, (N - n_coeffs) * 32);
+  scale_by_powers((fe*)out, n_coeffs, shift);
+  return fft_in_place((fe*)out, N, log_n, root_of_unity(log_n));
+}
+int orc_coset_intt(const u64* evals, size_t N, const u64* shift_, u64* out) {
+  int rc = orc_intt(evals, N, N, out);
+  if (rc) return rc;
+  fe shift, inv; memcpy(&shift, shift_, 32);
+  if (!fe_inverse(shift, &inv)) return ORC_ERR_ZERO_DENOMINATOR;
+  scale_by_powers((fe*)out, N, inv);
+  return ORC_OK;
+}
+int orc_quotient(const u64* const nums[], size_t count, const u64* alpha_, size_t n, size_t N, const u64* shift_, u64* out) {
+  int ln = log2_exact(n), lN = log2_exact(N);
+  if (ln < 0 || lN < 0) return ORC_ERR_NOT_POW2;
+  if (lN > TWO_ADICITY) return ORC_ERR_TWO_ADICITY;
+  if (n > N) return ORC_ERR_LENGTH;
+  fe alpha, shift; memcpy(&alpha, alpha_, 32); memcpy(&shift, shift_, 32);
+  size_t ratio = N / n;
+  fe* zinv = (fe*)malloc(ratio * sizeof(fe));
+  fe* acc = (fe*)malloc(N * sizeof(fe));
+  if (!zinv || !acc) { free(zinv); free(acc); return -8; }
+  fe gn = fe_pow_u64(shift, (u64)n), w = root_of_unity(lN - ln), wi = R_ONE;
+  for (size_t i = 0; i < ratio; ++i) {
+    fe zh = fe_sub(fe_mul(gn, wi), R_ONE);
+    if (!fe_inverse(zh, &zinv[i])) { free(zinv); free(acc); return ORC_ERR_ZERO_DENOMINATOR; }
+    wi = fe_mul(wi, w);
+  }
+  long total = (long)N;
+#pragma omp parallel for schedule(static)
+  for (long j = 0; j < total; ++j) {
+    fe a = {{0, 0, 0, 0}};
+    for (size_t i = count; i-- > 0;) { fe v; memcpy(&v, nums[i] + 4 * j, 32); a = fe_add(fe_mul(a, alpha), v); }
+    acc[j] = fe_mul(a, zinv[(size_t)j % ratio]);
+  }
+  int rc = orc_coset_intt((const u64*)acc, N, shift_, out);
+  free(zinv); free(acc);
+  return rc;
+}
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -57,6 +57,10 @@ SIGNATURES = {
     "plk_round23": (C.c_int, [C.c_void_p, u64pp, u64pp, u64pp, C.c_size_t, C.c_size_t, u64p, u64p, C.c_size_t, u64p, u64p, u64p]),
     "plk_gate_table_fill": (C.c_int, [C.c_void_p, u8p, u64pp, C.c_size_t, u64p, C.c_size_t, u64p, u64pp, u64pp]),
     "plk_dev_gate_table_fill": (C.c_int, [C.c_void_p, C.c_void_p, u8p, u64pp, C.c_size_t, u64p, C.c_size_t, u64p, u64pp, u64pp]),
+    "plk_coset_ntt": (C.c_int, [C.c_void_p, u64p, C.c_size_t, C.c_size_t, u64p, C.c_int, u64p]),
+    "plk_quotient": (C.c_int, [C.c_void_p, u64pp, C.c_size_t, u64p, C.c_size_t, C.c_size_t, u64p, u64p]),
+    "plk_dev_coset_ntt": (C.c_int, [C.c_void_p, C.c_void_p, u64pp, C.c_size_t, C.c_size_t, C.c_size_t, u64p, C.c_int, u64pp]),
+    "plk_dev_quotient": (C.c_int, [C.c_void_p, C.c_void_p, u64pp, C.c_size_t, u64p, C.c_size_t, C.c_size_t, u64p, u64p]),
     "plk_sigma_table": (C.c_int, [C.c_void_p, u64pp, C.c_size_t, u64pp]),
     "plk_dev_sigma_table": (C.c_int, [C.c_void_p, C.c_void_p, u64pp, C.c_size_t, u64pp]),
     "plk_dev_ntt_batch": (C.c_int, [C.c_void_p, C.c_void_p, u64pp, u32p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, u64pp]),

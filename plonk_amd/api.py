@@ -338,6 +338,49 @@ def build_permutation_constraint_evaluation_polynomial(polynomials: PermutationP
     return out
 
 
+#: F::multiplicative_generator() of BLS12-381 Fr: the coset shift ark-poly 0.3's coset_fft uses
+MULTIPLICATIVE_GENERATOR = 7
+
+
+def _shift(shift) -> np.ndarray:
+    if shift is None:
+        from .synth import ints_to_mont
+        return _fe(ints_to_mont([MULTIPLICATIVE_GENERATOR])[0])
+    return _fe(shift)
+
+
+def coset_fft(coeffs: np.ndarray, domain: Radix2EvaluationDomain, shift=None, ctx: Optional[Context] = None) -> np.ndarray:
+    """ark-poly `EvaluationDomain::coset_fft`: evaluations at shift * omega^i (shift defaults to the generator 7)."""
+    c = _ctx(ctx)
+    coeffs = _col(coeffs, "coeffs")
+    out = np.empty((domain.size(), 4), dtype=np.uint64)
+    c.check(c.lib.plk_coset_ntt(c.handle, _p(coeffs), coeffs.shape[0], domain.size(), _p(_shift(shift)), 0, _p(out)))
+    return out
+
+
+def coset_ifft(evals: np.ndarray, domain: Radix2EvaluationDomain, shift=None, ctx: Optional[Context] = None) -> np.ndarray:
+    """ark-poly `EvaluationDomain::coset_ifft`: coefficients from evaluations at shift * omega^i."""
+    c = _ctx(ctx)
+    evals = _col(evals, "evals")
+    out = np.empty((domain.size(), 4), dtype=np.uint64)
+    c.check(c.lib.plk_coset_ntt(c.handle, _p(evals), evals.shape[0], domain.size(), _p(_shift(shift)), 1, _p(out)))
+    return out
+
+
+def quotient_polynomial(numerators: Sequence[np.ndarray], alpha: np.ndarray, n_domain: Radix2EvaluationDomain,
+                        evaluation_domain: Radix2EvaluationDomain, shift=None, ctx: Optional[Context] = None) -> np.ndarray:
+    """Coefficients of (sum_i alpha^i numerators[i]) / (x^n - 1), the numerators being evaluation vectors on the
+    coset shift * <omega_N>.  Raises ZeroDenominator if x^n - 1 vanishes on that coset."""
+    c = _ctx(ctx)
+    nums = [_col(a, "numerator") for a in numerators]
+    N = evaluation_domain.size()
+    if any(a.shape[0] != N for a in nums):
+        raise LengthMismatch(_lib.PLK_ERR_LENGTH, "Evaluation length must match the domain size")
+    out = np.empty((N, 4), dtype=np.uint64)
+    c.check(c.lib.plk_quotient(c.handle, _table(nums), len(nums), _p(_fe(alpha)), n_domain.size(), N, _p(_shift(shift)), _p(out)))
+    return out
+
+
 def row_ops(kinds: Sequence[str], inputs: Sequence[int]) -> np.ndarray:
     """Row descriptors of the flattened trace: `ASTKind` index | number of inputs << 4, one byte per row."""
     k = np.array([AST_KINDS.index(x) for x in kinds], dtype=np.uint8)

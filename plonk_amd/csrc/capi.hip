@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -17,6 +18,7 @@
 #include "gate_table.cuh"
 #include "grand_product.cuh"
 #include "ntt.cuh"
+#include "quotient.cuh"
 #include "sigma_table.cuh"
 
 using namespace plk;
@@ -47,6 +49,8 @@ struct plk_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::map<std::pair<int, int>, NttPlan> plans;  // (log_n, inverse)
   std::map<std::string, DevBuf> ws;              // grow-only workspace slots
+  struct PowTable { DevBuf lo, hi; size_t hi_count = 0; };
+  std::map<std::array<uint64_t, 4>, PowTable> powers;   // g -> tables of g^j (coset transforms)
   size_t gp_rows = 0;                            // rows of the grand-product range held in the workspace
   GpStatus* status_dev = nullptr;
   GpStatus* status_host = nullptr;  // pinned
@@ -631,6 +635,117 @@ int launch_gate_table_fill(plk_ctx* ctx, hipStream_t s, const uint8_t* row_ops, 
   return PLK_OK;
 }
 
+// tables for g^j, j < count: lo[i] = g^i (i < 1024), hi[i] = g^(1024 i)
+int get_powers(plk_ctx* ctx, hipStream_t s, const Fe& g, size_t count, const uint64_t** lo, const uint64_t** hi) {
+  std::array<uint64_t, 4> key;
+  for (int i = 0; i < 4; ++i) key[i] = (uint64_t)g.l[2 * i] | ((uint64_t)g.l[2 * i + 1] << 32);
+  plk_ctx::PowTable& t = ctx->powers[key];
+  const size_t hi_count = std::max<size_t>((count + (1u << QT_LO_BITS) - 1) >> QT_LO_BITS, 1);
+  if (!t.lo.p) {
+    HIP_TRY(ctx, hipMalloc(&t.lo.p, (size_t)(1u << QT_LO_BITS) * ELEM));
+    hipLaunchKernelGGL(pow_table_kernel, dim3((1u << QT_LO_BITS) / 256), dim3(256), 0, s, (uint64_t*)t.lo.p, (uint64_t)(1u << QT_LO_BITS), g, 0);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  if (t.hi_count < hi_count) {
+    HIP_TRY(ctx, hipStreamSynchronize(s));                 // an older table may still be in use
+    if (t.hi.p) HIP_TRY(ctx, hipFree(t.hi.p));
+    t.hi.p = nullptr; t.hi_count = 0;
+    HIP_TRY(ctx, hipMalloc(&t.hi.p, hi_count * ELEM));
+    hipLaunchKernelGGL(pow_table_kernel, dim3((unsigned)((hi_count + 255) / 256)), dim3(256), 0, s, (uint64_t*)t.hi.p, (uint64_t)hi_count, g,
+                       QT_LO_BITS);
+    HIP_TRY(ctx, hipGetLastError());
+    t.hi_count = hi_count;
+    HIP_TRY(ctx, hipStreamSynchronize(s));                 // tables may be used from another stream later
+  }
+  *lo = (const uint64_t*)t.lo.p;
+  *hi = (const uint64_t*)t.hi.p;
+  return PLK_OK;
+}
+
+// ark-poly's coset_fft (inverse = false: n_in coefficients -> N evaluations on shift * <omega_N>) and
+// coset_ifft (inverse = true: N evaluations -> N coefficients), `batch` columns
+int launch_coset_ntt(plk_ctx* ctx, hipStream_t s, const uint64_t* const* in, size_t batch, size_t n_in, size_t N, const uint64_t shift_[4],
+                     bool inverse, uint64_t* const* out) {
+  int rc, log_n;
+  if ((rc = check_domain(ctx, N, &log_n))) return rc;
+  if (!shift_) return fail(ctx, PLK_ERR_ARG, "null pointer");
+  if (inverse ? n_in != N : n_in > N) return fail(ctx, PLK_ERR_LENGTH, plk_strerror(PLK_ERR_LENGTH));
+  if (batch == 0) return PLK_OK;
+  if (batch > NTT_MAX_BATCH) return fail(ctx, PLK_ERR_ARG, "batch exceeds PLK_MAX_BATCH");
+  const Fe shift = fe_from_limbs64(shift_);
+  if (!fe_is_canonical(shift) || fe_is_zero(shift)) return fail(ctx, PLK_ERR_ARG, "coset shift must be a non-zero reduced element");
+  const uint64_t *lo, *hi;
+  if ((rc = get_powers(ctx, s, inverse ? fe_inverse(shift) : shift, inverse ? N : n_in, &lo, &hi))) return rc;
+  for (size_t b = 0; b < batch; ++b) if (!in[b] || !out[b]) return fail(ctx, PLK_ERR_ARG, "null column pointer");
+  if (inverse) {
+    if ((rc = launch_ntt(ctx, s, in, nullptr, batch, N, N, true, out))) return rc;
+    for (size_t b = 0; b < batch; ++b) {
+      ProfScope ps(ctx, s, "scale_powers_kernel", 64.0 * (double)N);
+      hipLaunchKernelGGL(scale_powers_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, (const uint64_t*)out[b], (uint64_t)N, lo, hi, out[b]);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return PLK_OK;
+  }
+  void* tp;
+  if ((rc = ws_get(ctx, "coset_in", batch * std::max<size_t>(n_in, 1) * ELEM, &tp))) return rc;
+  const uint64_t* scaled[NTT_MAX_BATCH];
+  for (size_t b = 0; b < batch; ++b) {
+    uint64_t* dst = (uint64_t*)tp + b * n_in * 4;
+    scaled[b] = dst;
+    if (n_in) {
+      ProfScope ps(ctx, s, "scale_powers_kernel", 64.0 * (double)n_in);
+      hipLaunchKernelGGL(scale_powers_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, s, in[b], (uint64_t)n_in, lo, hi, dst);
+    }
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  return launch_ntt(ctx, s, scaled, nullptr, batch, n_in, N, false, out);
+}
+
+// coefficients (N) of (sum_i alpha^i nums[i]) / Z_H, nums being evaluation vectors on shift * <omega_N>
+int launch_quotient(plk_ctx* ctx, hipStream_t s, const uint64_t* const* nums, size_t count, const uint64_t alpha_[4], size_t n, size_t N,
+                    const uint64_t shift_[4], uint64_t* out) {
+  int rc, log_n, log_N;
+  if ((rc = check_domain(ctx, n, &log_n))) return rc;
+  if ((rc = check_domain(ctx, N, &log_N))) return rc;
+  if (n > N) return fail(ctx, PLK_ERR_LENGTH, "evaluation domain smaller than the trace domain");
+  if (!nums || !alpha_ || !shift_ || !out) return fail(ctx, PLK_ERR_ARG, "null pointer");
+  if (count == 0 || count > QT_MAX_NUMERATORS) return fail(ctx, PLK_ERR_ARG, "between 1 and 8 numerators");
+  if ((N >> log_n) > QT_MAX_RATIO) return fail(ctx, PLK_ERR_ARG, "evaluation domain more than 16 times the trace domain");
+  QuotientArgs a{};
+  a.count = (int)count;
+  a.ratio = (uint32_t)(N >> log_n);
+  a.alpha = fe_from_limbs64(alpha_);
+  const Fe shift = fe_from_limbs64(shift_);
+  if (!fe_is_canonical(a.alpha) || !fe_is_canonical(shift) || fe_is_zero(shift)) return fail(ctx, PLK_ERR_ARG, "alpha / shift not reduced mod p");
+  for (size_t i = 0; i < count; ++i) { if (!nums[i]) return fail(ctx, PLK_ERR_ARG, "null column pointer"); a.num[i] = nums[i]; }
+  // Z_H(shift * omega_N^j) = shift^n * omega_ratio^j - 1
+  const Fe gn = fe_pow_u64(shift, (uint64_t)n), w = root_of_unity(log_N - log_n);
+  Fe wi = fe_one();
+  for (uint32_t i = 0; i < QT_MAX_RATIO; ++i) {
+    if (i < a.ratio) {
+      const Fe zh = fe_sub(fe_mul(gn, wi), fe_one());
+      if (fe_is_zero(zh)) {
+        ctx->last_row = (long long)i;
+        return fail(ctx, PLK_ERR_ZERO_DENOMINATOR, "the vanishing polynomial is zero at point " + std::to_string(i) + " of this coset");
+      }
+      a.zinv[i] = fe_inverse(zh);
+      wi = fe_mul(wi, w);
+    } else {
+      a.zinv[i] = fe_zero();
+    }
+  }
+  void* tp;
+  if ((rc = ws_get(ctx, "quotient_evals", N * ELEM, &tp))) return rc;
+  {
+    ProfScope ps(ctx, s, "quotient_combine_kernel", 32.0 * (double)(count + 1) * (double)N);
+    hipLaunchKernelGGL(quotient_combine_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, a, (uint64_t)N, (uint64_t*)tp);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  const uint64_t* in[1] = {(const uint64_t*)tp};
+  uint64_t* o[1] = {out};
+  return launch_coset_ntt(ctx, s, in, 1, N, N, shift_, true, o);
+}
+
 // sigma table of n rows from node ids (device pointers), enqueued on s
 int launch_sigma_table(plk_ctx* ctx, hipStream_t s, const uint64_t* const node_ids[4], size_t n, uint64_t* const sigma_out[4]) {
   if (n == 0) return PLK_OK;
@@ -784,6 +899,7 @@ void plk_ctx_destroy(plk_ctx* ctx) {
     for (DevBuf* b : {&p.master, &p.hi, &p.hi_scaled, &p.lo, &p.scale, &p.from_u64, &p.full[0], &p.full[1], &p.prescale4}) if (b->p) (void)hipFree(b->p);
   }
   for (auto& kv : ctx->ws) if (kv.second.p) (void)hipFree(kv.second.p);
+  for (auto& kv : ctx->powers) { if (kv.second.lo.p) (void)hipFree(kv.second.lo.p); if (kv.second.hi.p) (void)hipFree(kv.second.hi.p); }
   for (auto& r : ctx->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   for (auto& e : ctx->event_pool) (void)hipEventDestroy(e);
   if (ctx->status_dev) (void)hipFree(ctx->status_dev);
@@ -913,6 +1029,25 @@ int plk_dev_grand_product_finish(plk_ctx* ctx, void* stream, size_t rows, const 
   if (rows == 0 || rows != ctx->gp_rows) return fail(ctx, PLK_ERR_ARG, "rows differ from the preceding plk_dev_grand_product_local");
   if ((rc = gp_apply_carries(ctx, (hipStream_t)stream, totals_all, ranges, mine))) return rc;
   return gp_finish(ctx, (hipStream_t)stream, z_after_out, nullptr);
+}
+
+int plk_dev_coset_ntt(plk_ctx* ctx, void* stream, const uint64_t* const* in, size_t batch, size_t n_in, size_t N, const uint64_t shift[4],
+                      int inverse, uint64_t* const* out) {
+  int rc = use_device(ctx);
+  if (rc) return rc;
+  if (!in || !out) return fail(ctx, PLK_ERR_ARG, "null pointer table");
+  for (size_t done = 0; done < batch; done += NTT_MAX_BATCH) {
+    const size_t m = std::min<size_t>(NTT_MAX_BATCH, batch - done);
+    if ((rc = launch_coset_ntt(ctx, (hipStream_t)stream, in + done, m, n_in, N, shift, inverse != 0, out + done))) return rc;
+  }
+  return PLK_OK;
+}
+
+int plk_dev_quotient(plk_ctx* ctx, void* stream, const uint64_t* const* numerators, size_t count, const uint64_t alpha[4], size_t n, size_t N,
+                     const uint64_t shift[4], uint64_t* coeffs_out) {
+  int rc = use_device(ctx);
+  if (rc) return rc;
+  return launch_quotient(ctx, (hipStream_t)stream, numerators, count, alpha, n, N, shift, coeffs_out);
 }
 
 int plk_dev_gate_table_fill(plk_ctx* ctx, void* stream, const uint8_t* row_ops, const uint64_t* const node_ids[4], size_t n,
@@ -1174,6 +1309,43 @@ int plk_grand_product(plk_ctx* ctx, const uint64_t* const wires[4], const uint64
   if ((rc = launch_grand_product(ctx, ctx->stream, w, sg, n, beta, gamma, (uint64_t*)dz))) return rc;
   if ((rc = fetch_status(ctx, ctx->stream))) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(z_out, dz, (n + 1) * ELEM, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return PLK_OK;
+}
+
+int plk_coset_ntt(plk_ctx* ctx, const uint64_t* in, size_t n_in, size_t domain_size, const uint64_t shift[4], int inverse, uint64_t* out) {
+  int rc = use_device(ctx);
+  if (rc) return rc;
+  if ((!in && n_in) || !out) return fail(ctx, PLK_ERR_ARG, "null pointer");
+  Staged st(ctx);
+  void *d_in, *d_out;
+  if ((rc = st.upload(in, n_in * ELEM, &d_in))) return rc;
+  if ((rc = st.alloc(domain_size * ELEM, &d_out))) return rc;
+  const uint64_t* ip[1] = {(const uint64_t*)d_in};
+  uint64_t* op[1] = {(uint64_t*)d_out};
+  if ((rc = launch_coset_ntt(ctx, ctx->stream, ip, 1, n_in, domain_size, shift, inverse != 0, op))) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(out, d_out, domain_size * ELEM, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return PLK_OK;
+}
+
+int plk_quotient(plk_ctx* ctx, const uint64_t* const* numerators, size_t count, const uint64_t alpha[4], size_t n, size_t N,
+                 const uint64_t shift[4], uint64_t* coeffs_out) {
+  int rc = use_device(ctx);
+  if (rc) return rc;
+  if (!numerators || !coeffs_out) return fail(ctx, PLK_ERR_ARG, "null pointer");
+  if (count == 0 || count > QT_MAX_NUMERATORS) return fail(ctx, PLK_ERR_ARG, "between 1 and 8 numerators");
+  Staged st(ctx);
+  const uint64_t* d[QT_MAX_NUMERATORS];
+  for (size_t i = 0; i < count; ++i) {
+    if (!numerators[i]) return fail(ctx, PLK_ERR_ARG, "null column pointer");
+    void* p; if ((rc = st.upload(numerators[i], N * ELEM, &p))) return rc;
+    d[i] = (const uint64_t*)p;
+  }
+  void* d_out;
+  if ((rc = st.alloc(N * ELEM, &d_out))) return rc;
+  if ((rc = launch_quotient(ctx, ctx->stream, d, count, alpha, n, N, shift, (uint64_t*)d_out))) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(coeffs_out, d_out, N * ELEM, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return PLK_OK;
 }

@@ -91,6 +91,24 @@ class DeviceProver:
                                                   1 if inverse else 0, _table(out)))
         return out
 
+    def coset_ntt(self, cols: Sequence[torch.Tensor], N: int, shift, inverse: bool = False, n_in: Optional[int] = None) -> List[torch.Tensor]:
+        """coset_fft (n_in coefficients -> N evaluations on shift * <omega_N>) or coset_ifft of each column."""
+        n_in = cols[0].shape[0] if n_in is None else n_in
+        out = [self.empty(N) for _ in cols]
+        sh = _host_fe(shift)
+        self.ctx.check(self.lib.plk_dev_coset_ntt(self.ctx.handle, self._stream(), _table(cols), len(cols), n_in, N,
+                                                  sh.ctypes.data_as(_lib.u64p), 1 if inverse else 0, _table(out)))
+        return out
+
+    def quotient(self, numerators: Sequence[torch.Tensor], alpha, n: int, shift) -> torch.Tensor:
+        """coefficients of (sum_i alpha^i numerators[i]) / (x^n - 1) from evaluation vectors on shift * <omega_N>."""
+        N = numerators[0].shape[0]
+        out = self.empty(N)
+        a, sh = _host_fe(alpha), _host_fe(shift)
+        self.ctx.check(self.lib.plk_dev_quotient(self.ctx.handle, self._stream(), _table(numerators), len(numerators),
+                                                 a.ctypes.data_as(_lib.u64p), n, N, sh.ctypes.data_as(_lib.u64p), _ptr(out)))
+        return out
+
     def gate_table_fill(self, ops: torch.Tensor, node_ids: Sequence[torch.Tensor], node_values: torch.Tensor, default_val,
                         kinds_present: Sequence[str] = AST_KINDS):
         """Gate evaluation table on device: `ops` `(n,) uint8`, node ids `(n,) int64`, `node_values` `(m, 4) int64`.
