@@ -37,7 +37,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log-n", type=int, default=20, help="log2 of the number of rows")
     ap.add_argument("--blowup", type=int, default=4, help="evaluation domain = blowup * n")
-    ap.add_argument("--workload", default="round23", choices=["round23", "ntt", "round23-sharded", "batch", "tables"],
+    ap.add_argument("--workload", default="round23", choices=["round23", "ntt", "round23-sharded", "batch", "tables", "quotient"],
                     help="round23: the headline metric (default). ntt: ONE four-step transform of 2^log-n points sharded over "
                          "the GPUs (config 4 with --log-n 24). round23-sharded: ONE proof over all GPUs. "
                          "batch: --circuits independent circuits dealt round-robin (config 5 with --log-n 18 --circuits 64)")
@@ -174,6 +174,37 @@ def other_workloads(args, prover, dist, rank, world):
             line["cpu_baseline"] = {"value": round((time.perf_counter() - t0) * 1e3, 2), "unit": "ms", "cores": 1, "kind": "port",
                                     "sample": f"the same 2^{args.log_n} rows: C restatement, sort-based grouping (the reference "
                                               f"groups with HashMaps)"}
+    elif args.workload == "quotient":
+        # the step after the path: two numerator vectors on the coset 7 * <omega_N> -> quotient coefficients
+        N = args.blowup * n
+        nums = [to_device(synth.random_elements(300 + 7 * rank + i, N), prover.device) for i in range(2)]
+        alpha, g7 = synth.random_elements(301, 1)[0], synth.ints_to_mont([7])[0]
+        out = prover.quotient(nums, alpha, n, g7)
+        prover.profile_begin()
+        dt = timed(lambda: prover.quotient(nums, alpha, n, g7), args.steps, args.warmup, dist, prover.device)
+        prof = prover.profile_end()
+        ms = dt * 1e3 / args.steps
+        alg = 32.0 * 3 * N                  # two numerators in, N coefficients out
+        line = dict(base, metric=f"quotient completion at n=2^{args.log_n}, N={args.blowup}n", value=round(ms, 4), unit="ms",
+                    ms_per_step=round(ms, 4), higher_is_better=False, scaling="weak", dtype="u32",
+                    config={"workload": f"(num_0 + alpha num_1) / (x^n - 1) on the coset 7<omega_N>, then coset_ifft of N=2^"
+                                        f"{args.log_n + args.blowup.bit_length() - 1} points, per GPU"},
+                    roofline={"bound": "hbm", "achieved": round(alg / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                              "note": "whole step; 96 algorithmic bytes per point"},
+                    kernels=[{"label": r["label"], "launches": r["launches"],
+                              "ms_per_step": round(r["total_ms"] / (args.steps + args.warmup), 4)} for r in prof])
+        if world == 1 and not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import c_oracle as co
+            from plonk_amd.device import to_host
+            host = [to_host(x) for x in nums]
+            co.set_num_threads(min(co.num_threads(), 16))
+            t0 = time.perf_counter()
+            ref = co.quotient(host, alpha, n, g7)
+            line["cpu_baseline"] = {"value": round((time.perf_counter() - t0) * 1e3, 1), "unit": "ms", "cores": min(co.num_threads(), 16),
+                                    "kind": "port", "sample": "the same workload, C restatement, transforms on OpenMP threads"}
+            line["matches_cpu"] = bool((to_host(out) == ref).all())
     elif args.workload == "round23-sharded":
         N = args.blowup * n
         c = synth.make_circuit(n, circuit_id=0)

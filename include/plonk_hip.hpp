@@ -320,6 +320,59 @@ inline Round23 prove_round23(const GateEvaluationTable& table, const Permutation
   return r;
 }
 
+// ---- the step after the path ------------------------------------------------------------------------
+
+// F::multiplicative_generator() of BLS12-381 Fr in Montgomery form (7 * R mod p): the shift ark-poly 0.3's
+// coset_fft / coset_ifft use
+inline Fr multiplicative_generator() {
+  uint64_t modulus[4], one[4], r2[4];
+  plk_field_constants(modulus, one, r2);
+  // 7 * one mod p by repeated addition (one < p < 2^255, so sums stay below 2^256 before each reduction)
+  auto add = [&](const Fr& a, const Fr& b) {
+    Fr s; unsigned __int128 c = 0;
+    for (int i = 0; i < 4; ++i) { c += (unsigned __int128)a[i] + b[i]; s[i] = (uint64_t)c; c >>= 64; }
+    bool ge = true;
+    for (int i = 3; i >= 0; --i) if (s[i] != modulus[i]) { ge = s[i] > modulus[i]; break; }
+    if (ge) { unsigned __int128 bo = 0; for (int i = 0; i < 4; ++i) { unsigned __int128 d = (unsigned __int128)s[i] - modulus[i] - bo; s[i] = (uint64_t)d; bo = (d >> 64) & 1; } }
+    return s;
+  };
+  const Fr o{one[0], one[1], one[2], one[3]};
+  Fr g = o;
+  for (int i = 1; i < 7; ++i) g = add(g, o);
+  return g;
+}
+
+// ark-poly EvaluationDomain::coset_fft: evaluations of the polynomial at shift * omega^i
+inline std::vector<Fr> coset_fft(const std::vector<Fr>& coeffs, const GeneralEvaluationDomain& domain, const Fr& shift = multiplicative_generator(),
+                                 Context& ctx = Context::global()) {
+  std::vector<Fr> out(domain.size());
+  ctx.check(plk_coset_ntt(ctx.get(), detail::ptr(coeffs), coeffs.size(), domain.size(), shift.data(), 0, detail::ptr(out)));
+  return out;
+}
+
+// ark-poly EvaluationDomain::coset_ifft
+inline std::vector<Fr> coset_ifft(const std::vector<Fr>& evals, const GeneralEvaluationDomain& domain, const Fr& shift = multiplicative_generator(),
+                                  Context& ctx = Context::global()) {
+  std::vector<Fr> out(domain.size());
+  ctx.check(plk_coset_ntt(ctx.get(), detail::ptr(evals), evals.size(), domain.size(), shift.data(), 1, detail::ptr(out)));
+  return out;
+}
+
+// (sum_i alpha^i numerators[i]) / (x^n - 1) from evaluation vectors on the coset shift * <omega_N>; the reference
+// stops before this step (README.md:15-17)
+inline DensePolynomial quotient_polynomial(const std::vector<std::vector<Fr>>& numerators, const Fr& alpha,
+                                           const GeneralEvaluationDomain& n_domain, const GeneralEvaluationDomain& evaluation_domain,
+                                           const Fr& shift = multiplicative_generator(), Context& ctx = Context::global()) {
+  std::vector<const uint64_t*> p;
+  for (const auto& v : numerators) {
+    if (v.size() != evaluation_domain.size()) throw LengthMismatch(PLK_ERR_LENGTH, plk_strerror(PLK_ERR_LENGTH));
+    p.push_back(detail::ptr(v));
+  }
+  std::vector<Fr> out(evaluation_domain.size());
+  ctx.check(plk_quotient(ctx.get(), p.data(), p.size(), alpha.data(), n_domain.size(), evaluation_domain.size(), shift.data(), detail::ptr(out)));
+  return DensePolynomial::from_coefficients_vec(std::move(out));
+}
+
 // The execution trace flattened for the two table-building steps: global rows numbered as
 // OffsetTable::build numbers them (src/offset_table.rs:22-48), one node id per wire (PLK_NO_WIRE where the
 // operation lacks the wire), PLK_ROW_OP(kind, inputs) per row, and the evaluated value of every node.

@@ -26,6 +26,8 @@ int orc_perm_constraints(const u64* z_coeffs, const u64* const sigma_coeffs[4], 
 int orc_round23(const u64* const wires[4], const u64* const sel[9], const u64* const sigma[4], size_t n, size_t N, const u64* beta,
                 const u64* gamma, size_t z_shift, u64* z_out, u64* gate_out, u64* perm_out, int64_t* bad_row);
 int orc_sigma_table(const u64* const node_ids[4], size_t n, u64* const sigma_out[4]);
+int orc_coset_ntt(const u64* coeffs, size_t n_coeffs, size_t N, const u64* shift, u64* out);
+int orc_quotient(const u64* const nums[], size_t count, const u64* alpha, size_t n, size_t N, const u64* shift, u64* out);
 int orc_gate_table_fill(const uint8_t* row_ops, const u64* const node_ids[4], size_t n, const u64* node_values, size_t n_values,
                         const u64* default_val, u64* const wires_out[4], u64* const sel_out[9]);
 }
@@ -222,6 +224,32 @@ static void test_tables_from_a_trace() {
   CHECK(pt.sigma1 == sg_ref[0] && pt.sigma2 == sg_ref[1] && pt.sigma3 == sg_ref[2] && pt.sigma_output == sg_ref[3]);
 }
 
+static void test_quotient_step() {
+  std::printf("test_quotient_step\n");
+  const size_t n = 256, N = 1024;
+  const Fr g = multiplicative_generator();
+  CHECK(g == from_int(7));
+  sm_state = 606;
+  const std::vector<Fr> f = random_column(3 * n);
+  const std::vector<Fr> ev = coset_fft(f, GeneralEvaluationDomain(N));
+  std::vector<Fr> ev_ref(N);
+  CHECK(orc_coset_ntt(f[0].data(), f.size(), N, g.data(), ev_ref[0].data()) == 0);
+  CHECK(ev == ev_ref);
+  std::vector<Fr> back = coset_ifft(ev, GeneralEvaluationDomain(N));
+  back.resize(f.size());
+  CHECK(back == f);
+  const std::vector<std::vector<Fr>> nums = {random_column(N), random_column(N)};
+  const Fr alpha = random_fr();
+  const DensePolynomial t = quotient_polynomial(nums, alpha, GeneralEvaluationDomain(n), GeneralEvaluationDomain(N));
+  std::vector<Fr> t_ref(N);
+  const u64* np[2] = {nums[0][0].data(), nums[1][0].data()};
+  CHECK(orc_quotient(np, 2, alpha.data(), n, N, g.data(), t_ref[0].data()) == 0);
+  CHECK(padded(t, N) == t_ref);
+  bool threw = false;                      // x^n - 1 vanishes on the plain subgroup
+  try { quotient_polynomial(nums, alpha, GeneralEvaluationDomain(n), GeneralEvaluationDomain(N), from_int(1)); } catch (const ZeroDenominator&) { threw = true; }
+  CHECK(threw);
+}
+
 int main() {
   test_evaluations_to_dense_polynomial();
   test_round_2_and_3_function_by_function(4, 16, 9);
@@ -230,6 +258,7 @@ int main() {
   test_round_2_and_3_function_by_function(1 << 13, 1 << 15, 4);     // a subset of the selector kinds
   test_panics_become_exceptions();
   test_tables_from_a_trace();
+  test_quotient_step();
   std::printf("%d failure(s)\n", failures);
   return failures;
 }
