@@ -179,6 +179,26 @@ int plk_coset_ntt(plk_ctx* ctx, const uint64_t* in, size_t n_in, size_t domain_s
 int plk_quotient(plk_ctx* ctx, const uint64_t* const* numerators, size_t count, const uint64_t alpha[4], size_t n, size_t N,
                  const uint64_t shift[4], uint64_t* coeffs_out);
 
+/* ---- commitments: multi-scalar multiplication in BLS12-381 G1 ------------------------------ */
+
+/* The reference imports `ark_poly_commit::kzg10` (src/main.rs:9) and stops there (README.md:15-17:
+ * "Implement commitment scheme" unchecked).  A KZG10 commitment of a polynomial is
+ * sum_i coeff_i * powers_of_g[i] (`KZG10::commit` -> `VariableBaseMSM::multi_scalar_mul`); these entry
+ * points compute that sum.
+ *  - A G1 point crosses the ABI in affine form as 12 uint64_t: x then y, each the memory of ark-ff
+ *    `Fp384` (6 little-endian Montgomery limbs, R = 2^384); (0, 0) stands for the point at infinity.
+ *  - plk_msm_set_bases copies n affine bases (the powers of tau) to the GPU once; they stay with the
+ *    context.  plk_dev_msm_set_bases uses a caller-owned device table instead (not copied, not freed).
+ *  - plk_msm_g1 / plk_dev_msm_g1: scalars are n field elements in the usual form (Montgomery Fr), on the
+ *    host / on the device; n must not exceed the number of bases.  The affine result is written to host
+ *    memory; the call waits for the stream (the last ~300 point operations are serial and run on the host).
+ *  - plk_dev_g1_multiples writes (first + i) * base, i < count, as affine points to device memory
+ *    (test and benchmark set-up: a table whose discrete logarithms are known).
+ * Run time depends on the scalars only through how evenly their 16-bit digits spread: one thread adds up
+ * each bucket, so n equal scalars serialise. */
+int plk_msm_set_bases(plk_ctx* ctx, const uint64_t* bases_host, size_t n);
+int plk_msm_g1(plk_ctx* ctx, const uint64_t* scalars_host, size_t n, uint64_t out_xy[12]);
+
 /* ---- device entry points (same arithmetic, device pointers, asynchronous) ---------------- */
 
 /* `batch` transforms of size N in one set of launches.  in[b] holds n_in valid elements
@@ -215,6 +235,10 @@ int plk_dev_mul(plk_ctx* ctx, void* stream, const uint64_t* a, const uint64_t* b
  * No counterpart in the reference (ark-poly runs one shared-memory FFT). */
 int plk_dev_twiddle_block(plk_ctx* ctx, void* stream, size_t N, int inverse, int scale_by_inverse_n, size_t rows, size_t cols,
                           size_t row0, size_t col0, uint64_t* out);
+
+int plk_dev_msm_set_bases(plk_ctx* ctx, const uint64_t* bases_dev, size_t n);
+int plk_dev_msm_g1(plk_ctx* ctx, void* stream, const uint64_t* scalars_dev, size_t n, uint64_t out_xy[12]);
+int plk_dev_g1_multiples(plk_ctx* ctx, void* stream, const uint64_t base_xy[12], uint64_t first, size_t count, uint64_t* out_dev);
 
 /* plk_coset_ntt for `batch` device columns, plk_quotient on device vectors (alpha, shift stay host pointers) */
 int plk_dev_coset_ntt(plk_ctx* ctx, void* stream, const uint64_t* const* in, size_t batch, size_t n_in, size_t N,

@@ -381,6 +381,24 @@ def quotient_polynomial(numerators: Sequence[np.ndarray], alpha: np.ndarray, n_d
     return out
 
 
+def msm_set_bases(bases: np.ndarray, ctx: Optional[Context] = None) -> None:
+    """Copy the affine G1 bases (`(n, 12) uint64`: x then y, Montgomery Fp384 limbs; (0, 0) = infinity) to the GPU."""
+    c = _ctx(ctx)
+    b = np.ascontiguousarray(bases, dtype=np.uint64)
+    if b.ndim != 2 or b.shape[1] != 12:
+        raise ValueError(f"bases: expected (n, 12) uint64, got {b.shape}")
+    c.check(c.lib.plk_msm_set_bases(c.handle, _p(b), b.shape[0]))
+
+
+def msm_g1(scalars: np.ndarray, ctx: Optional[Context] = None) -> np.ndarray:
+    """sum_i scalars[i] * bases[i] (`VariableBaseMSM::multi_scalar_mul`, the body of `KZG10::commit`): `(12,) uint64`."""
+    c = _ctx(ctx)
+    s = _col(scalars, "scalars")
+    out = np.zeros((12,), dtype=np.uint64)
+    c.check(c.lib.plk_msm_g1(c.handle, _p(s), s.shape[0], _p(out)))
+    return out
+
+
 def row_ops(kinds: Sequence[str], inputs: Sequence[int]) -> np.ndarray:
     """Row descriptors of the flattened trace: `ASTKind` index | number of inputs << 4, one byte per row."""
     k = np.array([AST_KINDS.index(x) for x in kinds], dtype=np.uint8)

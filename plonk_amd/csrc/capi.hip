@@ -17,6 +17,7 @@
 #include "field.cuh"
 #include "gate_table.cuh"
 #include "grand_product.cuh"
+#include "msm.cuh"
 #include "ntt.cuh"
 #include "quotient.cuh"
 #include "sigma_table.cuh"
@@ -51,6 +52,9 @@ struct plk_ctx {
   std::map<std::string, DevBuf> ws;              // grow-only workspace slots
   struct PowTable { DevBuf lo, hi; size_t hi_count = 0; };
   std::map<std::array<uint64_t, 4>, PowTable> powers;   // g -> tables of g^j (coset transforms)
+  uint64_t* msm_bases = nullptr;                 // affine G1 table on the device (owned unless msm_bases_borrowed)
+  size_t msm_nbases = 0;
+  bool msm_bases_borrowed = false;
   size_t gp_rows = 0;                            // rows of the grand-product range held in the workspace
   GpStatus* status_dev = nullptr;
   GpStatus* status_host = nullptr;  // pinned
@@ -747,6 +751,55 @@ int launch_quotient(plk_ctx* ctx, hipStream_t s, const uint64_t* const* nums, si
 }
 
 // sigma table of n rows from node ids (device pointers), enqueued on s
+// Workspace and launches of the stable radix sort of (uint64 key, uint32 value) pairs (sigma_table.cuh).
+// The caller fills pairs.keys[0] / vals[0] and ORs every key into *or_bits (zeroed by pair_sort_alloc);
+// after pair_sort_run the sorted pairs are in buffer sig_buffer_before(or_bits, 8).
+struct PairSort {
+  SigPairs pairs;
+  uint64_t* or_bits;
+  uint32_t *hist, *sums;
+  uint32_t waves, scan_tiles;
+  uint64_t entries, total;
+};
+
+int pair_sort_alloc(plk_ctx* ctx, hipStream_t s, const std::string& prefix, uint64_t total, PairSort* ps) {
+  ps->total = total;
+  ps->waves = (uint32_t)((total + SIG_CHUNK - 1) / SIG_CHUNK);
+  ps->entries = (uint64_t)SIG_BINS * ps->waves;
+  ps->scan_tiles = (uint32_t)((ps->entries + SIG_SCAN_TILE - 1) / SIG_SCAN_TILE);
+  int rc;
+  void *pk, *pv, *ph;
+  if ((rc = ws_get(ctx, prefix + "_keys", 2 * total * 8, &pk))) return rc;
+  if ((rc = ws_get(ctx, prefix + "_vals", 2 * total * 4, &pv))) return rc;
+  if ((rc = ws_get(ctx, prefix + "_hist", 8 + (ps->entries + ps->scan_tiles) * 4, &ph))) return rc;
+  ps->pairs.keys[0] = (uint64_t*)pk; ps->pairs.keys[1] = (uint64_t*)pk + total;
+  ps->pairs.vals[0] = (uint32_t*)pv; ps->pairs.vals[1] = (uint32_t*)pv + total;
+  ps->or_bits = (uint64_t*)ph;             // 8-byte aligned head of the slot
+  ps->hist = (uint32_t*)((char*)ph + 8);
+  ps->sums = ps->hist + ps->entries;
+  HIP_TRY(ctx, hipMemsetAsync(ps->or_bits, 0, 8, s));
+  return PLK_OK;
+}
+
+int pair_sort_run(plk_ctx* ctx, hipStream_t s, const PairSort& ps, double alg_per_pass) {
+  // eight digit passes are enqueued; a pass whose digit is zero in every key returns at once
+  for (int pass = 0; pass < 8; ++pass) {
+    const std::string ptag = "/p" + std::to_string(pass);
+    { ProfScope p(ctx, s, "sig_hist_kernel" + ptag, alg_per_pass / 3);
+      hipLaunchKernelGGL(sig_hist_kernel, dim3(ps.waves), dim3(64), 0, s, ps.pairs, ps.total, pass, (const uint64_t*)ps.or_bits, ps.hist, ps.waves); }
+    { ProfScope p(ctx, s, "sig_scan_kernel" + ptag, alg_per_pass / 3);
+      hipLaunchKernelGGL(sig_scan_tiles_kernel, dim3(ps.scan_tiles), dim3(SIG_SCAN_THREADS), 0, s, ps.hist, ps.entries, ps.sums, pass,
+                         (const uint64_t*)ps.or_bits);
+      hipLaunchKernelGGL(sig_scan_sums_kernel, dim3(1), dim3(SIG_SCAN_THREADS), 0, s, ps.sums, ps.scan_tiles, pass, (const uint64_t*)ps.or_bits); }
+    ProfScope p(ctx, s, "sig_scatter_kernel" + ptag, alg_per_pass / 3);
+    hipLaunchKernelGGL(sig_scatter_kernel, dim3(ps.waves), dim3(64), 0, s, ps.pairs, ps.total, pass, (const uint64_t*)ps.or_bits,
+                       (const uint32_t*)ps.hist, (const uint32_t*)ps.sums, ps.waves);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  return PLK_OK;
+}
+
+// sigma table of n rows from node ids (device pointers), enqueued on s
 int launch_sigma_table(plk_ctx* ctx, hipStream_t s, const uint64_t* const node_ids[4], size_t n, uint64_t* const sigma_out[4]) {
   if (n == 0) return PLK_OK;
   if (n > (size_t(1) << 30)) return fail(ctx, PLK_ERR_ARG, "sigma table: more than 2^30 rows");
@@ -757,46 +810,89 @@ int launch_sigma_table(plk_ctx* ctx, hipStream_t s, const uint64_t* const node_i
     cols.sigma[k] = sigma_out[k];
   }
   const uint64_t total = 4 * (uint64_t)n;
-  const uint32_t waves = (uint32_t)((total + SIG_CHUNK - 1) / SIG_CHUNK);
-  const uint64_t entries = (uint64_t)SIG_BINS * waves;
   int rc;
-  void *pk, *pv, *ph;
-  if ((rc = ws_get(ctx, "sig_keys", 2 * total * 8, &pk))) return rc;
-  if ((rc = ws_get(ctx, "sig_vals", 2 * total * 4, &pv))) return rc;
-  const uint32_t scan_tiles = (uint32_t)((entries + SIG_SCAN_TILE - 1) / SIG_SCAN_TILE);
-  if ((rc = ws_get(ctx, "sig_hist", 8 + (entries + scan_tiles) * 4, &ph))) return rc;
-  SigPairs pairs;
-  pairs.keys[0] = (uint64_t*)pk; pairs.keys[1] = (uint64_t*)pk + total;
-  pairs.vals[0] = (uint32_t*)pv; pairs.vals[1] = (uint32_t*)pv + total;
-  uint64_t* or_bits = (uint64_t*)ph;             // 8-byte aligned head of the slot
-  uint32_t* hist = (uint32_t*)((char*)ph + 8);
-  uint32_t* sums = hist + entries;
-  HIP_TRY(ctx, hipMemsetAsync(or_bits, 0, 8, s));
-  const unsigned ew_blocks = (unsigned)((total + 255) / 256);
+  PairSort ps;
+  if ((rc = pair_sort_alloc(ctx, s, "sig", total, &ps))) return rc;
   // algorithmic bytes: 4 node ids in and 4 row indices out per row, in equal shares over the 10 steps
   const double alg = (32.0 * (double)n + 32.0 * (double)n) / 10.0;
   {
-    ProfScope ps(ctx, s, "sig_keys_kernel", alg);
-    hipLaunchKernelGGL(sig_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, cols, (uint64_t)n, pairs.keys[0], pairs.vals[0], or_bits);
+    ProfScope p(ctx, s, "sig_keys_kernel", alg);
+    hipLaunchKernelGGL(sig_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, cols, (uint64_t)n, ps.pairs.keys[0], ps.pairs.vals[0],
+                       ps.or_bits);
     HIP_TRY(ctx, hipGetLastError());
   }
-  // eight digit passes are enqueued; a pass whose digit is zero in every node id returns at once
-  for (int pass = 0; pass < 8; ++pass) {
-    const std::string ptag = "/p" + std::to_string(pass);
-    { ProfScope ps(ctx, s, "sig_hist_kernel" + ptag, alg / 3);
-      hipLaunchKernelGGL(sig_hist_kernel, dim3(waves), dim3(64), 0, s, pairs, total, pass, (const uint64_t*)or_bits, hist, waves); }
-    { ProfScope ps(ctx, s, "sig_scan_kernel" + ptag, alg / 3);
-      hipLaunchKernelGGL(sig_scan_tiles_kernel, dim3(scan_tiles), dim3(SIG_SCAN_THREADS), 0, s, hist, entries, sums, pass, (const uint64_t*)or_bits);
-      hipLaunchKernelGGL(sig_scan_sums_kernel, dim3(1), dim3(SIG_SCAN_THREADS), 0, s, sums, scan_tiles, pass, (const uint64_t*)or_bits); }
-    ProfScope ps(ctx, s, "sig_scatter_kernel" + ptag, alg / 3);
-    hipLaunchKernelGGL(sig_scatter_kernel, dim3(waves), dim3(64), 0, s, pairs, total, pass, (const uint64_t*)or_bits,
-                       (const uint32_t*)hist, (const uint32_t*)sums, waves);
+  if ((rc = pair_sort_run(ctx, s, ps, alg))) return rc;
+  {
+    ProfScope p(ctx, s, "sig_link_kernel", alg);
+    hipLaunchKernelGGL(sig_link_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ps.pairs, (const uint64_t*)ps.or_bits, total, cols);
     HIP_TRY(ctx, hipGetLastError());
+  }
+  return PLK_OK;
+}
+
+// ---- commitments: multi-scalar multiplication in G1 (msm.cuh)
+
+int msm_window_bits(size_t n) { return n >= (size_t(1) << 18) ? 16 : n >= (size_t(1) << 14) ? 13 : n >= (size_t(1) << 10) ? 10 : 7; }
+
+// sum_i scalars[i] * bases[i], i < n, scalars on the device (Montgomery Fr), bases = the context's table;
+// the affine result (x, y; (0, 0) = infinity) goes to host memory.  Waits for the stream.
+int launch_msm(plk_ctx* ctx, hipStream_t s, const uint64_t* scalars, size_t n, uint64_t out_xy[12]) {
+  if (!scalars || !out_xy) return fail(ctx, PLK_ERR_ARG, "null pointer");
+  if (!ctx->msm_bases || n > ctx->msm_nbases) return fail(ctx, PLK_ERR_LENGTH, "more scalars than bases set with plk_msm_set_bases");
+  if (n >= (size_t(1) << 28)) return fail(ctx, PLK_ERR_ARG, "msm: more than 2^28 terms");
+  for (int i = 0; i < 12; ++i) out_xy[i] = 0;
+  if (n == 0) return PLK_OK;
+  const int c = msm_window_bits(n), windows = (255 + c - 1) / c;
+  const uint64_t total = (uint64_t)n * windows, nbuckets = (uint64_t)windows << c;
+  int rc;
+  PairSort ps;
+  if ((rc = pair_sort_alloc(ctx, s, "msm", total, &ps))) return rc;
+  void *pf, *pb, *pc, *pw;
+  if ((rc = ws_get(ctx, "msm_bounds", 2 * nbuckets * 4, &pf))) return rc;
+  if ((rc = ws_get(ctx, "msm_buckets", nbuckets * 144, &pb))) return rc;
+  const uint64_t chunks = nbuckets / MSM_CHUNK, chunks_per_window = chunks / windows;
+  if ((rc = ws_get(ctx, "msm_chunks", chunks * 144, &pc))) return rc;
+  if ((rc = ws_get(ctx, "msm_windows", (size_t)windows * 144, &pw))) return rc;
+  uint32_t* first = (uint32_t*)pf; uint32_t* last = first + nbuckets;
+  HIP_TRY(ctx, hipMemsetAsync(pf, 0, 2 * nbuckets * 4, s));
+  {
+    ProfScope p(ctx, s, "msm_digits_kernel", 32.0 * (double)n);
+    hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scalars, (uint64_t)n, c, windows, ps.pairs.keys[0],
+                       ps.pairs.vals[0], ps.or_bits);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  if ((rc = pair_sort_run(ctx, s, ps, 0.0))) return rc;
+  {
+    ProfScope p(ctx, s, "msm_bounds_kernel", 0.0);
+    hipLaunchKernelGGL(msm_bounds_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ps.pairs, (const uint64_t*)ps.or_bits, total, first, last);
   }
   {
-    ProfScope ps(ctx, s, "sig_link_kernel", alg);
-    hipLaunchKernelGGL(sig_link_kernel, dim3(ew_blocks), dim3(256), 0, s, pairs, (const uint64_t*)or_bits, total, cols);
-    HIP_TRY(ctx, hipGetLastError());
+    ProfScope p(ctx, s, "msm_bucket_sum_kernel", 96.0 * (double)total);   // one affine base per pair
+    hipLaunchKernelGGL(msm_bucket_sum_kernel, dim3((unsigned)((nbuckets + 255) / 256)), dim3(256), 0, s, ps.pairs, (const uint64_t*)ps.or_bits,
+                       (const uint32_t*)first, (const uint32_t*)last, nbuckets, (const uint64_t*)ctx->msm_bases, (uint64_t*)pb);
+  }
+  {
+    ProfScope p(ctx, s, "msm_chunk_kernel", 144.0 * (double)nbuckets);
+    hipLaunchKernelGGL(msm_chunk_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, s, (const uint64_t*)pb, nbuckets, c, (uint64_t*)pc);
+  }
+  {
+    ProfScope p(ctx, s, "msm_reduce_kernel", 144.0 * (double)chunks);
+    hipLaunchKernelGGL(msm_reduce_kernel, dim3((unsigned)windows), dim3(MSM_REDUCE_THREADS), 0, s, (const uint64_t*)pc, chunks_per_window, (uint64_t*)pw);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  std::vector<G1Jac> w(windows);
+  HIP_TRY(ctx, hipMemcpyAsync(w.data(), pw, (size_t)windows * 144, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  // serial tail on the host: Horner over the windows, then one inversion
+  G1Jac acc = g1_inf();
+  for (int k = windows - 1; k >= 0; --k) {
+    for (int d = 0; d < c; ++d) acc = g1_double(acc);
+    acc = g1_add(acc, w[k]);
+  }
+  const G1Affine r = g1_to_affine(acc);
+  for (int i = 0; i < 6; ++i) {
+    out_xy[i] = (uint64_t)r.x.l[2 * i] | ((uint64_t)r.x.l[2 * i + 1] << 32);
+    out_xy[6 + i] = (uint64_t)r.y.l[2 * i] | ((uint64_t)r.y.l[2 * i + 1] << 32);
   }
   return PLK_OK;
 }
@@ -899,6 +995,7 @@ void plk_ctx_destroy(plk_ctx* ctx) {
     for (DevBuf* b : {&p.master, &p.hi, &p.hi_scaled, &p.lo, &p.scale, &p.from_u64, &p.full[0], &p.full[1], &p.prescale4}) if (b->p) (void)hipFree(b->p);
   }
   for (auto& kv : ctx->ws) if (kv.second.p) (void)hipFree(kv.second.p);
+  if (ctx->msm_bases && !ctx->msm_bases_borrowed) (void)hipFree(ctx->msm_bases);
   for (auto& kv : ctx->powers) { if (kv.second.lo.p) (void)hipFree(kv.second.lo.p); if (kv.second.hi.p) (void)hipFree(kv.second.hi.p); }
   for (auto& r : ctx->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   for (auto& e : ctx->event_pool) (void)hipEventDestroy(e);
@@ -1029,6 +1126,38 @@ int plk_dev_grand_product_finish(plk_ctx* ctx, void* stream, size_t rows, const 
   if (rows == 0 || rows != ctx->gp_rows) return fail(ctx, PLK_ERR_ARG, "rows differ from the preceding plk_dev_grand_product_local");
   if ((rc = gp_apply_carries(ctx, (hipStream_t)stream, totals_all, ranges, mine))) return rc;
   return gp_finish(ctx, (hipStream_t)stream, z_after_out, nullptr);
+}
+
+int plk_dev_msm_set_bases(plk_ctx* ctx, const uint64_t* bases_dev, size_t n) {
+  int rc = use_device(ctx);
+  if (rc) return rc;
+  if (!bases_dev && n) return fail(ctx, PLK_ERR_ARG, "null pointer");
+  if (ctx->msm_bases && !ctx->msm_bases_borrowed) HIP_TRY(ctx, hipFree(ctx->msm_bases));
+  ctx->msm_bases = const_cast<uint64_t*>(bases_dev);
+  ctx->msm_nbases = n;
+  ctx->msm_bases_borrowed = true;
+  return PLK_OK;
+}
+
+int plk_dev_msm_g1(plk_ctx* ctx, void* stream, const uint64_t* scalars_dev, size_t n, uint64_t out_xy[12]) {
+  int rc = use_device(ctx);
+  if (rc) return rc;
+  return launch_msm(ctx, (hipStream_t)stream, scalars_dev, n, out_xy);
+}
+
+int plk_dev_g1_multiples(plk_ctx* ctx, void* stream, const uint64_t base_xy[12], uint64_t first, size_t count, uint64_t* out_dev) {
+  int rc = use_device(ctx);
+  if (rc) return rc;
+  if (!base_xy || (!out_dev && count)) return fail(ctx, PLK_ERR_ARG, "null pointer");
+  if (count == 0) return PLK_OK;
+  G1Affine b;
+  for (int i = 0; i < 6; ++i) {
+    b.x.l[2 * i] = (uint32_t)base_xy[i]; b.x.l[2 * i + 1] = (uint32_t)(base_xy[i] >> 32);
+    b.y.l[2 * i] = (uint32_t)base_xy[6 + i]; b.y.l[2 * i + 1] = (uint32_t)(base_xy[6 + i] >> 32);
+  }
+  hipLaunchKernelGGL(g1_multiples_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, b, first, (uint64_t)count, out_dev);
+  HIP_TRY(ctx, hipGetLastError());
+  return PLK_OK;
 }
 
 int plk_dev_coset_ntt(plk_ctx* ctx, void* stream, const uint64_t* const* in, size_t batch, size_t n_in, size_t N, const uint64_t shift[4],
@@ -1311,6 +1440,29 @@ int plk_grand_product(plk_ctx* ctx, const uint64_t* const wires[4], const uint64
   HIP_TRY(ctx, hipMemcpyAsync(z_out, dz, (n + 1) * ELEM, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return PLK_OK;
+}
+
+int plk_msm_set_bases(plk_ctx* ctx, const uint64_t* bases_host, size_t n) {
+  int rc = use_device(ctx);
+  if (rc) return rc;
+  if (!bases_host && n) return fail(ctx, PLK_ERR_ARG, "null pointer");
+  if (ctx->msm_bases && !ctx->msm_bases_borrowed) HIP_TRY(ctx, hipFree(ctx->msm_bases));
+  ctx->msm_bases = nullptr; ctx->msm_nbases = 0; ctx->msm_bases_borrowed = false;
+  if (n == 0) return PLK_OK;
+  HIP_TRY(ctx, hipMalloc((void**)&ctx->msm_bases, n * 96));
+  HIP_TRY(ctx, hipMemcpy(ctx->msm_bases, bases_host, n * 96, hipMemcpyHostToDevice));
+  ctx->msm_nbases = n;
+  return PLK_OK;
+}
+
+int plk_msm_g1(plk_ctx* ctx, const uint64_t* scalars_host, size_t n, uint64_t out_xy[12]) {
+  int rc = use_device(ctx);
+  if (rc) return rc;
+  if (!scalars_host && n) return fail(ctx, PLK_ERR_ARG, "null pointer");
+  Staged st(ctx);
+  void* d;
+  if ((rc = st.upload(scalars_host, n * ELEM, &d))) return rc;
+  return launch_msm(ctx, ctx->stream, (const uint64_t*)d, n, out_xy);
 }
 
 int plk_coset_ntt(plk_ctx* ctx, const uint64_t* in, size_t n_in, size_t domain_size, const uint64_t shift[4], int inverse, uint64_t* out) {

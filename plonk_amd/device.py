@@ -91,6 +91,24 @@ class DeviceProver:
                                                   1 if inverse else 0, _table(out)))
         return out
 
+    def g1_multiples(self, base_xy: np.ndarray, first: int, count: int) -> torch.Tensor:
+        """`(count, 12) int64` affine points (first + i) * base on the device."""
+        out = torch.empty((count, 12), dtype=torch.int64, device=self.device)
+        b = np.ascontiguousarray(base_xy, dtype=np.uint64).reshape(12)
+        self.ctx.check(self.lib.plk_dev_g1_multiples(self.ctx.handle, self._stream(), b.ctypes.data_as(_lib.u64p), first, count, _ptr(out)))
+        return out
+
+    def msm_set_bases(self, bases: torch.Tensor) -> None:
+        """Use a device table of affine bases (kept alive by this object) for the following msm calls."""
+        self._msm_bases = bases.contiguous()
+        self.ctx.check(self.lib.plk_dev_msm_set_bases(self.ctx.handle, _ptr(self._msm_bases), self._msm_bases.shape[0]))
+
+    def msm(self, scalars: torch.Tensor) -> np.ndarray:
+        """sum_i scalars[i] * bases[i] for device scalars `(n, 4) int64`; returns the affine point `(12,) uint64` (host)."""
+        out = np.zeros((12,), dtype=np.uint64)
+        self.ctx.check(self.lib.plk_dev_msm_g1(self.ctx.handle, self._stream(), _ptr(scalars), scalars.shape[0], out.ctypes.data_as(_lib.u64p)))
+        return out
+
     def coset_ntt(self, cols: Sequence[torch.Tensor], N: int, shift, inverse: bool = False, n_in: Optional[int] = None) -> List[torch.Tensor]:
         """coset_fft (n_in coefficients -> N evaluations on shift * <omega_N>) or coset_ifft of each column."""
         n_in = cols[0].shape[0] if n_in is None else n_in
