@@ -37,7 +37,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log-n", type=int, default=20, help="log2 of the number of rows")
     ap.add_argument("--blowup", type=int, default=4, help="evaluation domain = blowup * n")
-    ap.add_argument("--workload", default="round23", choices=["round23", "ntt", "round23-sharded", "batch", "tables", "quotient"],
+    ap.add_argument("--workload", default="round23", choices=["round23", "ntt", "round23-sharded", "batch", "tables", "quotient", "msm"],
                     help="round23: the headline metric (default). ntt: ONE four-step transform of 2^log-n points sharded over "
                          "the GPUs (config 4 with --log-n 24). round23-sharded: ONE proof over all GPUs. "
                          "batch: --circuits independent circuits dealt round-robin (config 5 with --log-n 18 --circuits 64)")
@@ -205,6 +205,43 @@ def other_workloads(args, prover, dist, rank, world):
             line["cpu_baseline"] = {"value": round((time.perf_counter() - t0) * 1e3, 1), "unit": "ms", "cores": min(co.num_threads(), 16),
                                     "kind": "port", "sample": "the same workload, C restatement, transforms on OpenMP threads"}
             line["matches_cpu"] = bool((to_host(out) == ref).all())
+    elif args.workload == "msm":
+        # commitment of one polynomial: sum_i coeff_i * base_i in BLS12-381 G1, bases (i + 1) * G resident on the GPU
+        import numpy as np
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import g1_oracle as g1
+        gen = np.array(g1.fq_to_mont_limbs(g1.GX) + g1.fq_to_mont_limbs(g1.GY), dtype=np.uint64)
+        bases = prover.g1_multiples(gen, 1, n)
+        prover.msm_set_bases(bases)
+        s_host = synth.random_elements(500 + rank, n)
+        s_dev = to_device(s_host, prover.device)
+        out = prover.msm(s_dev)
+        prover.profile_begin()
+        dt = timed(lambda: prover.msm(s_dev), args.steps, args.warmup, dist, prover.device)
+        prof = prover.profile_end()
+        ms = dt * 1e3 / args.steps
+        alg = (32.0 + 96.0) * n                     # one scalar and one affine base per term
+        line = dict(base, metric=f"G1 multi-scalar multiplication of 2^{args.log_n} terms (one KZG commitment)", value=round(ms, 4),
+                    unit="ms", ms_per_step=round(ms, 4), higher_is_better=False, scaling="weak", dtype="u32",
+                    config={"workload": f"sum of 2^{args.log_n} scalar * point products in BLS12-381 G1 per GPU, bases resident, "
+                                        f"result (affine) on the host"},
+                    terms_per_s=round(n / (ms * 1e-3), 1),
+                    roofline={"bound": "hbm", "achieved": round(alg / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                              "note": "whole step; 128 algorithmic bytes per term; the work is ~190 base-field products per "
+                                      "term (one mixed addition per term and window), i.e. bound by integer multiply-add issue"},
+                    kernels=[{"label": r["label"], "launches": r["launches"],
+                              "ms_per_step": round(r["total_ms"] / (args.steps + args.warmup), 4)} for r in prof])
+        if world == 1 and not args.no_cpu_baseline:
+            import c_oracle as co
+            from plonk_amd.device import to_host
+            co.set_num_threads(min(co.num_threads(), 16))
+            b_host = to_host(bases)
+            t0 = time.perf_counter()
+            ref = co.g1_msm(s_host, b_host)
+            line["cpu_baseline"] = {"value": round((time.perf_counter() - t0) * 1e3, 1), "unit": "ms", "cores": min(co.num_threads(), 16),
+                                    "kind": "port", "sample": "the same terms, C bucket method, windows on OpenMP threads"}
+            line["matches_cpu"] = bool((out == ref).all())
     elif args.workload == "round23-sharded":
         N = args.blowup * n
         c = synth.make_circuit(n, circuit_id=0)

@@ -202,3 +202,10 @@ def quotient(numerators, alpha, n, shift):
     nums = [_c(a) for a in numerators]; N = nums[0].shape[0]; out = np.empty((N, 4), dtype=np.uint64)
     _chk(lib().orc_quotient(_tab(nums), C.c_size_t(len(nums)), _p(_c(alpha)), C.c_size_t(n), C.c_size_t(N), _p(_c(shift)), _p(out)))
     return out
+
+
+def g1_msm(scalars, bases):
+    """orc_g1_msm: scalars `(n, 4) uint64` (Montgomery Fr), bases `(n, 12) uint64` affine -> `(12,) uint64` affine point."""
+    s = _c(scalars); b = _c(bases); out = np.zeros(12, dtype=np.uint64)
+    assert b.shape[0] >= s.shape[0]
+    _chk(lib().orc_g1_msm(_p(s), _p(b), C.c_size_t(s.shape[0]), _p(out))); return out

@@ -84,3 +84,14 @@ def test_msm_degenerate(prover, ctx):
     with pytest.raises(pa.LengthMismatch):                                            # more scalars than bases
         pa.msm_g1(synth.ints_to_mont([1, 2, 3]), ctx=ctx)
     assert limbs_to_point(pa.msm_g1(synth.ints_to_mont([]).reshape(0, 4), ctx=ctx)) is None
+
+
+def test_msm_vs_c_oracle(prover):
+    """2^14 terms over a table that does not start at G, against the C restatement of the bucket method."""
+    import c_oracle as co
+    n = 1 << 14
+    bases = prover.g1_multiples(G, 0x123456789ABCDEF, n)
+    prover.msm_set_bases(bases)
+    s = synth.random_elements(4242, n)
+    got = prover.msm(to_device(s, prover.device))
+    assert np.array_equal(got, co.g1_msm(s, to_host(bases)))
