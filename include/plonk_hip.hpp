@@ -373,6 +373,26 @@ inline DensePolynomial quotient_polynomial(const std::vector<std::vector<Fr>>& n
   return DensePolynomial::from_coefficients_vec(std::move(out));
 }
 
+// ---- commitments.  ark-ec `GroupAffine<g1::Parameters>` of BLS12-381 as its memory: x then y, 6 Montgomery limbs each
+// (`Fp384`), all zero for the point at infinity.  The reference imports ark_poly_commit::kzg10 (src/main.rs:9) and has no
+// commitment code (README.md:15-17); `KZG10::commit` is multi_scalar_mul(powers_of_g, coefficients).
+using G1Affine = std::array<uint64_t, 12>;
+
+// the bases stay on the GPU with the context (the powers of tau are fixed per circuit size)
+inline void msm_set_bases(const std::vector<G1Affine>& bases, Context& ctx = Context::global()) {
+  ctx.check(plk_msm_set_bases(ctx.get(), bases.empty() ? nullptr : bases[0].data(), bases.size()));
+}
+
+// ark-ec VariableBaseMSM::multi_scalar_mul(bases, scalars) over the first scalars.size() bases set above
+inline G1Affine multi_scalar_mul(const std::vector<Fr>& scalars, Context& ctx = Context::global()) {
+  G1Affine out;
+  ctx.check(plk_msm_g1(ctx.get(), detail::ptr(scalars), scalars.size(), out.data()));
+  return out;
+}
+
+// KZG10::commit without hiding: the commitment of a polynomial under the bases set above
+inline G1Affine commit(const DensePolynomial& polynomial, Context& ctx = Context::global()) { return multi_scalar_mul(polynomial.coeffs, ctx); }
+
 // The execution trace flattened for the two table-building steps: global rows numbered as
 // OffsetTable::build numbers them (src/offset_table.rs:22-48), one node id per wire (PLK_NO_WIRE where the
 // operation lacks the wire), PLK_ROW_OP(kind, inputs) per row, and the evaluated value of every node.

@@ -28,6 +28,7 @@ int orc_round23(const u64* const wires[4], const u64* const sel[9], const u64* c
 int orc_sigma_table(const u64* const node_ids[4], size_t n, u64* const sigma_out[4]);
 int orc_coset_ntt(const u64* coeffs, size_t n_coeffs, size_t N, const u64* shift, u64* out);
 int orc_quotient(const u64* const nums[], size_t count, const u64* alpha, size_t n, size_t N, const u64* shift, u64* out);
+int orc_g1_msm(const u64* scalars, const u64* bases, size_t n, u64* out_xy);
 int orc_gate_table_fill(const uint8_t* row_ops, const u64* const node_ids[4], size_t n, const u64* node_values, size_t n_values,
                         const u64* default_val, u64* const wires_out[4], u64* const sel_out[9]);
 }
@@ -250,6 +251,32 @@ static void test_quotient_step() {
   CHECK(threw);
 }
 
+static void test_commitment() {
+  std::printf("test_commitment\n");
+  // the generator of BLS12-381 G1 in ark-ec's affine memory (Montgomery x, y)
+  const G1Affine gen = {0x5cb38790fd530c16ull, 0x7817fc679976fff5ull, 0x154f95c7143ba1c1ull, 0xf0ae6acdf3d0e747ull, 0xedce6ecc21dbf440ull, 0x120177419e0bfb75ull, 0xbaac93d50ce72271ull, 0x8c22631a7918fd8eull, 0xdd595f13570725ceull, 0x51ac582950405194ull, 0x0e1c8c3fad0059c0ull, 0x0bbc3efc5008a26aull};
+  const size_t n = 300;
+  std::vector<G1Affine> bases(n);                    // (i + 1)^2 * G, by the oracle, plus one point at infinity
+  for (size_t i = 0; i < n; ++i) {
+    const Fr k = from_int((i + 1) * (i + 1));
+    CHECK(orc_g1_msm(k.data(), gen.data(), 1, bases[i].data()) == 0);
+  }
+  bases[17].fill(0);
+  msm_set_bases(bases);
+  sm_state = 707;
+  DensePolynomial f = DensePolynomial::from_coefficients_vec(random_column(n));
+  f.coeffs[3] = from_int(0); f.coeffs[4] = from_int(1);
+  G1Affine want;
+  CHECK(orc_g1_msm(f.coeffs[0].data(), bases[0].data(), n, want.data()) == 0);
+  CHECK(commit(f) == want);
+  const std::vector<Fr> few(f.coeffs.begin(), f.coeffs.begin() + 5);   // fewer scalars than bases
+  CHECK(orc_g1_msm(few[0].data(), bases[0].data(), few.size(), want.data()) == 0);
+  CHECK(multi_scalar_mul(few) == want);
+  bool threw = false;
+  try { multi_scalar_mul(random_column(n + 1)); } catch (const Error&) { threw = true; }
+  CHECK(threw);
+}
+
 int main() {
   test_evaluations_to_dense_polynomial();
   test_round_2_and_3_function_by_function(4, 16, 9);
@@ -259,6 +286,7 @@ int main() {
   test_panics_become_exceptions();
   test_tables_from_a_trace();
   test_quotient_step();
+  test_commitment();
   std::printf("%d failure(s)\n", failures);
   return failures;
 }
