@@ -52,9 +52,9 @@ struct plk_ctx {
   std::map<std::string, DevBuf> ws;              // grow-only workspace slots
   struct PowTable { DevBuf lo, hi; size_t hi_count = 0; };
   std::map<std::array<uint64_t, 4>, PowTable> powers;   // g -> tables of g^j (coset transforms)
-  uint64_t* msm_bases = nullptr;                 // affine G1 table on the device (owned unless msm_bases_borrowed)
+  uint64_t* msm_table = nullptr;                 // affine G1 points 2^(c w) * base_i at [w * msm_nbases + i] (msm.cuh)
   size_t msm_nbases = 0;
-  bool msm_bases_borrowed = false;
+  int msm_c = 0;                                 // window width the table was built for
   size_t gp_rows = 0;                            // rows of the grand-product range held in the workspace
   GpStatus* status_dev = nullptr;
   GpStatus* status_host = nullptr;  // pinned
@@ -832,33 +832,67 @@ int launch_sigma_table(plk_ctx* ctx, hipStream_t s, const uint64_t* const node_i
 
 // ---- commitments: multi-scalar multiplication in G1 (msm.cuh)
 
-int msm_window_bits(size_t n) { return n >= (size_t(1) << 18) ? 16 : n >= (size_t(1) << 14) ? 13 : n >= (size_t(1) << 10) ? 10 : 7; }
+// window width for a table of nb bases: about log2(nb) bits, so that the 2^c buckets get a few entries each even
+// when only one window's worth of digits lands in them
+int msm_window_bits(size_t nb) {
+  int c = 4;
+  while (c < MSM_MAX_WINDOW_BITS && (size_t(1) << (c + 1)) <= nb) ++c;
+  return c;
+}
+
+void msm_free_table(plk_ctx* ctx) {
+  if (ctx->msm_table) (void)hipFree(ctx->msm_table);
+  ctx->msm_table = nullptr; ctx->msm_nbases = 0;
+}
+
+// table[w * nb + i] = 2^(c w) * bases[i] for the device array `bases` (msm.cuh); replaces the context's table
+int msm_build_table(plk_ctx* ctx, hipStream_t s, const uint64_t* bases, size_t nb) {
+  msm_free_table(ctx);
+  if (nb == 0) return PLK_OK;
+  if (nb >= (size_t(1) << 26)) return fail(ctx, PLK_ERR_ARG, "msm: more than 2^26 bases");
+  const int c = msm_window_bits(nb), windows = (255 + c - 1) / c;
+  const size_t slots = nb * (size_t)windows;
+  uint64_t *zs = nullptr, *prods = nullptr;
+  HIP_TRY(ctx, hipMalloc((void**)&ctx->msm_table, slots * 96));
+  hipError_t e = hipMalloc((void**)&zs, slots * 48);
+  if (e == hipSuccess) e = hipMalloc((void**)&prods, slots * 48);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(msm_table_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, bases, (uint64_t)nb, c, windows, ctx->msm_table, zs, prods);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (zs) (void)hipFree(zs);
+  if (prods) (void)hipFree(prods);
+  if (e != hipSuccess) { msm_free_table(ctx); HIP_TRY(ctx, e); }
+  ctx->msm_nbases = nb; ctx->msm_c = c;
+  return PLK_OK;
+}
 
 // sum_i scalars[i] * bases[i], i < n, scalars on the device (Montgomery Fr), bases = the context's table;
 // the affine result (x, y; (0, 0) = infinity) goes to host memory.  Waits for the stream.
 int launch_msm(plk_ctx* ctx, hipStream_t s, const uint64_t* scalars, size_t n, uint64_t out_xy[12]) {
   if (!scalars || !out_xy) return fail(ctx, PLK_ERR_ARG, "null pointer");
-  if (!ctx->msm_bases || n > ctx->msm_nbases) return fail(ctx, PLK_ERR_LENGTH, "more scalars than bases set with plk_msm_set_bases");
-  if (n >= (size_t(1) << 28)) return fail(ctx, PLK_ERR_ARG, "msm: more than 2^28 terms");
+  if (n > ctx->msm_nbases) return fail(ctx, PLK_ERR_LENGTH, "more scalars than bases set with plk_msm_set_bases");
   for (int i = 0; i < 12; ++i) out_xy[i] = 0;
   if (n == 0) return PLK_OK;
-  const int c = msm_window_bits(n), windows = (255 + c - 1) / c;
-  const uint64_t total = (uint64_t)n * windows, nbuckets = (uint64_t)windows << c;
+  const int c = ctx->msm_c, windows = (255 + c - 1) / c;
+  const uint64_t total = (uint64_t)n * windows, nbuckets = 1ull << c;
+  // lanes per bucket: about 32 entries each (the lanes' partial sums cost log2(lanes) full additions to combine)
+  int log_t = 0;
+  while (log_t < 6 && (total >> (c + log_t + 1)) >= 32) ++log_t;
   int rc;
   PairSort ps;
   if ((rc = pair_sort_alloc(ctx, s, "msm", total, &ps))) return rc;
-  void *pf, *pb, *pc, *pw;
+  void *pf, *pb, *pa;
   if ((rc = ws_get(ctx, "msm_bounds", 2 * nbuckets * 4, &pf))) return rc;
   if ((rc = ws_get(ctx, "msm_buckets", nbuckets * 144, &pb))) return rc;
-  const uint64_t chunks = nbuckets / MSM_CHUNK, chunks_per_window = chunks / windows;
-  if ((rc = ws_get(ctx, "msm_chunks", chunks * 144, &pc))) return rc;
-  if ((rc = ws_get(ctx, "msm_windows", (size_t)windows * 144, &pw))) return rc;
+  if ((rc = ws_get(ctx, "msm_fold", 2 * 256 * 144, &pa))) return rc;
   uint32_t* first = (uint32_t*)pf; uint32_t* last = first + nbuckets;
   HIP_TRY(ctx, hipMemsetAsync(pf, 0, 2 * nbuckets * 4, s));
   {
     ProfScope p(ctx, s, "msm_digits_kernel", 32.0 * (double)n);
-    hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scalars, (uint64_t)n, c, windows, ps.pairs.keys[0],
-                       ps.pairs.vals[0], ps.or_bits);
+    hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scalars, (uint64_t)n, (uint64_t)ctx->msm_nbases, c,
+                       windows, ps.pairs.keys[0], ps.pairs.vals[0], ps.or_bits);
     HIP_TRY(ctx, hipGetLastError());
   }
   if ((rc = pair_sort_run(ctx, s, ps, 0.0))) return rc;
@@ -867,29 +901,26 @@ int launch_msm(plk_ctx* ctx, hipStream_t s, const uint64_t* scalars, size_t n, u
     hipLaunchKernelGGL(msm_bounds_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ps.pairs, (const uint64_t*)ps.or_bits, total, first, last);
   }
   {
-    ProfScope p(ctx, s, "msm_bucket_sum_kernel", 96.0 * (double)total);   // one affine base per pair
-    hipLaunchKernelGGL(msm_bucket_sum_kernel, dim3((unsigned)((nbuckets + 255) / 256)), dim3(256), 0, s, ps.pairs, (const uint64_t*)ps.or_bits,
-                       (const uint32_t*)first, (const uint32_t*)last, nbuckets, (const uint64_t*)ctx->msm_bases, (uint64_t*)pb);
+    ProfScope p(ctx, s, "msm_bucket_sum_kernel", 96.0 * (double)total);   // one affine table entry per pair
+    hipLaunchKernelGGL(msm_bucket_sum_kernel, dim3((unsigned)(((nbuckets << log_t) + 255) / 256)), dim3(256), 0, s, ps.pairs,
+                       (const uint64_t*)ps.or_bits, (const uint32_t*)first, (const uint32_t*)last, nbuckets, log_t, (const uint64_t*)ctx->msm_table,
+                       (uint64_t*)pb);
   }
-  {
-    ProfScope p(ctx, s, "msm_chunk_kernel", 144.0 * (double)nbuckets);
-    hipLaunchKernelGGL(msm_chunk_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, s, (const uint64_t*)pb, nbuckets, c, (uint64_t*)pc);
-  }
-  {
-    ProfScope p(ctx, s, "msm_reduce_kernel", 144.0 * (double)chunks);
-    hipLaunchKernelGGL(msm_reduce_kernel, dim3((unsigned)windows), dim3(MSM_REDUCE_THREADS), 0, s, (const uint64_t*)pc, chunks_per_window, (uint64_t*)pw);
+  // folds: 2^c points -> 2^ceil(c/2) -> ... -> 2; then sum_d d * B_d = B_1
+  const uint64_t* in = (const uint64_t*)pb;
+  uint64_t* pp[2] = {(uint64_t*)pa, (uint64_t*)pa + 256 * 18};
+  int cc = c, flip = 0;
+  while (cc > 1) {
+    const int next = cc - (cc >> 1);
+    ProfScope p(ctx, s, "msm_fold_kernel", 144.0 * (double)(1ull << cc));
+    hipLaunchKernelGGL(msm_fold_kernel, dim3(1u << next), dim3(MSM_FOLD_THREADS), 0, s, in, cc, pp[flip]);
+    in = pp[flip]; flip ^= 1; cc = next;
   }
   HIP_TRY(ctx, hipGetLastError());
-  std::vector<G1Jac> w(windows);
-  HIP_TRY(ctx, hipMemcpyAsync(w.data(), pw, (size_t)windows * 144, hipMemcpyDeviceToHost, s));
+  G1Jac sum;
+  HIP_TRY(ctx, hipMemcpyAsync(&sum, in + 18, 144, hipMemcpyDeviceToHost, s));
   HIP_TRY(ctx, hipStreamSynchronize(s));
-  // serial tail on the host: Horner over the windows, then one inversion
-  G1Jac acc = g1_inf();
-  for (int k = windows - 1; k >= 0; --k) {
-    for (int d = 0; d < c; ++d) acc = g1_double(acc);
-    acc = g1_add(acc, w[k]);
-  }
-  const G1Affine r = g1_to_affine(acc);
+  const G1Affine r = g1_to_affine(sum);      // one base-field inversion, on the host
   for (int i = 0; i < 6; ++i) {
     out_xy[i] = (uint64_t)r.x.l[2 * i] | ((uint64_t)r.x.l[2 * i + 1] << 32);
     out_xy[6 + i] = (uint64_t)r.y.l[2 * i] | ((uint64_t)r.y.l[2 * i + 1] << 32);
@@ -995,7 +1026,7 @@ void plk_ctx_destroy(plk_ctx* ctx) {
     for (DevBuf* b : {&p.master, &p.hi, &p.hi_scaled, &p.lo, &p.scale, &p.from_u64, &p.full[0], &p.full[1], &p.prescale4}) if (b->p) (void)hipFree(b->p);
   }
   for (auto& kv : ctx->ws) if (kv.second.p) (void)hipFree(kv.second.p);
-  if (ctx->msm_bases && !ctx->msm_bases_borrowed) (void)hipFree(ctx->msm_bases);
+  msm_free_table(ctx);
   for (auto& kv : ctx->powers) { if (kv.second.lo.p) (void)hipFree(kv.second.lo.p); if (kv.second.hi.p) (void)hipFree(kv.second.hi.p); }
   for (auto& r : ctx->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   for (auto& e : ctx->event_pool) (void)hipEventDestroy(e);
@@ -1132,11 +1163,8 @@ int plk_dev_msm_set_bases(plk_ctx* ctx, const uint64_t* bases_dev, size_t n) {
   int rc = use_device(ctx);
   if (rc) return rc;
   if (!bases_dev && n) return fail(ctx, PLK_ERR_ARG, "null pointer");
-  if (ctx->msm_bases && !ctx->msm_bases_borrowed) HIP_TRY(ctx, hipFree(ctx->msm_bases));
-  ctx->msm_bases = const_cast<uint64_t*>(bases_dev);
-  ctx->msm_nbases = n;
-  ctx->msm_bases_borrowed = true;
-  return PLK_OK;
+  HIP_TRY(ctx, hipDeviceSynchronize());          // the caller's table may have been written on any stream
+  return msm_build_table(ctx, ctx->stream, bases_dev, n);
 }
 
 int plk_dev_msm_g1(plk_ctx* ctx, void* stream, const uint64_t* scalars_dev, size_t n, uint64_t out_xy[12]) {
@@ -1446,13 +1474,14 @@ int plk_msm_set_bases(plk_ctx* ctx, const uint64_t* bases_host, size_t n) {
   int rc = use_device(ctx);
   if (rc) return rc;
   if (!bases_host && n) return fail(ctx, PLK_ERR_ARG, "null pointer");
-  if (ctx->msm_bases && !ctx->msm_bases_borrowed) HIP_TRY(ctx, hipFree(ctx->msm_bases));
-  ctx->msm_bases = nullptr; ctx->msm_nbases = 0; ctx->msm_bases_borrowed = false;
-  if (n == 0) return PLK_OK;
-  HIP_TRY(ctx, hipMalloc((void**)&ctx->msm_bases, n * 96));
-  HIP_TRY(ctx, hipMemcpy(ctx->msm_bases, bases_host, n * 96, hipMemcpyHostToDevice));
-  ctx->msm_nbases = n;
-  return PLK_OK;
+  if (n == 0) { msm_free_table(ctx); return PLK_OK; }
+  uint64_t* d = nullptr;
+  HIP_TRY(ctx, hipMalloc((void**)&d, n * 96));
+  hipError_t e = hipMemcpy(d, bases_host, n * 96, hipMemcpyHostToDevice);
+  rc = e == hipSuccess ? msm_build_table(ctx, ctx->stream, d, n) : PLK_OK;
+  (void)hipFree(d);
+  HIP_TRY(ctx, e);
+  return rc;
 }
 
 int plk_msm_g1(plk_ctx* ctx, const uint64_t* scalars_host, size_t n, uint64_t out_xy[12]) {

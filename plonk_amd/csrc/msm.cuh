@@ -1,16 +1,19 @@
-// Multi-scalar multiplication in BLS12-381 G1 by the bucket method: sum_i s_i * P_i, the body of a
-// KZG10 commitment (s = polynomial coefficients, P = powers of tau in G1).
+// Multi-scalar multiplication in BLS12-381 G1 by the bucket method over a precomputed table:
+// sum_i s_i * P_i, the body of a KZG10 commitment (s = polynomial coefficients, P = powers of tau in G1).
 //
 // The reference only imports `ark_poly_commit::kzg10` (src/main.rs:9); commitments are listed as not
-// implemented (README.md:15-17).  Steps, all on the device except the last:
+// implemented (README.md:15-17).  The bases are fixed per circuit size, so when they are set the table
+// T[w][i] = 2^(c w) * P_i (affine, W = ceil(255 / c) windows) is built once; with it digit d of window w of
+// scalar i contributes d * T[w][i], and ALL windows share one set of 2^c buckets:
 //   1. every scalar (Montgomery form, as ark-ff keeps it) is made canonical and cut into W digits of c bits;
-//      digit d != 0 of window w gives the pair (key = w * 2^c + d, value = scalar index);
+//      digit d != 0 of window w gives the pair (key = d, value = w * nb + i);
 //   2. the pairs are sorted by key (the stable radix sort of sigma_table.cuh);
-//   3. one thread per bucket adds up its run of points (mixed additions);
-//   4. per window, sum_d d * B_d: threads take chunks of MSM_CHUNK buckets (running sums), the chunk
-//      results are added up by a tree per window;
-//   5. the W window sums go to the host, which combines them (c doublings per window) and converts
-//      the result to affine coordinates - a strictly serial tail of ~300 point operations.
+//   3. a fixed number of adjacent lanes per bucket add up its run of table entries (mixed additions) and
+//      combine their partial sums through lane shuffles;
+//   4. sum_d d * B_d by folding: with d = hi * 2^h + lo, sum_d d B_d = sum_k k (2^h R_k + C_k), R_k / C_k the
+//      row / column sums of B seen as a matrix - plain sums (trees), and the same problem on 2^ceil(c/2)
+//      points; after about log2(c) folds two points are left and the second is the result;
+//   5. the host converts that one point to affine coordinates (one base-field inversion).
 #pragma once
 #include "field.cuh"
 #include "g1.cuh"
@@ -18,12 +21,13 @@
 
 namespace plk {
 
-constexpr int MSM_CHUNK = 16;           // buckets per thread in step 4
-constexpr int MSM_REDUCE_THREADS = 256;
+constexpr int MSM_FOLD_THREADS = 512;
+constexpr int MSM_MAX_WINDOW_BITS = 16;   // a fold handles a matrix of at most 256 x 256 buckets
 
-// step 1: keys[w * n + i], vals[w * n + i] for scalar i, window w; also the OR of all keys (for the sort)
-__global__ __launch_bounds__(256) void msm_digits_kernel(const uint64_t* scalars, uint64_t n, int c, int windows, uint64_t* keys,
-                                                         uint32_t* vals, uint64_t* or_bits) {
+// step 1: keys[w * n + i] = digit w of scalar i, vals[w * n + i] = its table entry w * nb + i; also the OR of all
+// keys (for the sort)
+__global__ __launch_bounds__(256) void msm_digits_kernel(const uint64_t* scalars, uint64_t n, uint64_t nb, int c, int windows,
+                                                         uint64_t* keys, uint32_t* vals, uint64_t* or_bits) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   uint64_t seen = 0;
   if (i < n) {
@@ -34,9 +38,9 @@ __global__ __launch_bounds__(256) void msm_digits_kernel(const uint64_t* scalars
       uint64_t chunk = s.l[limb];
       if (limb + 1 < 8) chunk |= (uint64_t)s.l[limb + 1] << 32;
       const uint64_t d = (chunk >> off) & ((1ull << c) - 1);
-      const uint64_t key = d ? (((uint64_t)w << c) | d) : SIG_NO_WIRE;
+      const uint64_t key = d ? d : SIG_NO_WIRE;
       keys[(uint64_t)w * n + i] = key;
-      vals[(uint64_t)w * n + i] = (uint32_t)i;
+      vals[(uint64_t)w * n + i] = (uint32_t)((uint64_t)w * nb + i);
       if (d) seen |= key;
     }
   }
@@ -58,51 +62,96 @@ __global__ __launch_bounds__(256) void msm_bounds_kernel(SigPairs pairs, const u
   if (p + 1 == total || keys[p + 1] != key) last[key] = (uint32_t)p + 1;
 }
 
-// step 3: bucket b = sum of bases[vals[p]] over its run
+// step 3: bucket b = sum of table[vals[p]] over its run; 2^log_t adjacent lanes share a bucket (entry j, j + 2^log_t, ...
+// each) and add their partial sums up by shuffles, so that long runs do not serialise on one lane
+__device__ __forceinline__ Fq fq_shfl_down(const Fq& a, int delta) {
+  Fq r;
+#pragma unroll
+  for (int k = 0; k < 12; ++k) r.l[k] = __shfl_down(a.l[k], delta);
+  return r;
+}
+
 __global__ __launch_bounds__(256) void msm_bucket_sum_kernel(SigPairs pairs, const uint64_t* or_bits, const uint32_t* first,
-                                                             const uint32_t* last, uint64_t nbuckets, const uint64_t* bases,
+                                                             const uint32_t* last, uint64_t nbuckets, int log_t, const uint64_t* table,
                                                              uint64_t* buckets) {
-  const uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (b >= nbuckets) return;
+  const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t b = gid >> log_t;
+  const uint32_t j = (uint32_t)gid & ((1u << log_t) - 1), t = 1u << log_t;
   const uint32_t* vals = pairs.vals[sig_buffer_before(or_bits, 8)];
   G1Jac acc = g1_inf();
-  for (uint32_t p = first[b]; p < last[b]; ++p) acc = g1_add_affine(acc, g1_load_affine(bases, vals[p]));
-  g1_store_jac(buckets, b, acc);
-}
-
-// step 4a: thread t handles buckets [lo, lo + MSM_CHUNK) of one window (all inside it: 2^c is a multiple of the
-// chunk): out[t] = sum_d d' * B_d with d' the digit value (bucket index within its window)
-__global__ __launch_bounds__(256) void msm_chunk_kernel(const uint64_t* buckets, uint64_t nbuckets, int c, uint64_t* out) {
-  const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  const uint64_t lo = t * MSM_CHUNK;
-  if (lo >= nbuckets) return;
-  G1Jac run = g1_inf(), acc = g1_inf();
-  for (int k = MSM_CHUNK - 1; k >= 1; --k) {          // acc = sum_k k * B_{lo+k}
-    run = g1_add(run, g1_load_jac(buckets, lo + k));
-    acc = g1_add(acc, run);
+  if (b < nbuckets) {
+    const uint32_t end = last[b];
+    for (uint32_t p = first[b] + j; p < end; p += t) acc = g1_add_affine(acc, g1_load_affine(table, vals[p]));
   }
-  run = g1_add(run, g1_load_jac(buckets, lo));         // run = sum of the chunk
-  const uint64_t digit0 = lo & ((1ull << c) - 1);      // digit value of the chunk's first bucket
-  if (digit0) acc = g1_add(acc, g1_mul_u64(run, digit0));
-  g1_store_jac(out, t, acc);
+  for (uint32_t step = t >> 1; step >= 1; step >>= 1) {      // whole waves get here: shuffles need every lane
+    G1Jac other;
+    other.x = fq_shfl_down(acc.x, step); other.y = fq_shfl_down(acc.y, step); other.z = fq_shfl_down(acc.z, step);
+    if (j + step >= t) other.z = fq_zero();                    // a lane of the next bucket: not ours
+    acc = g1_add(acc, other);
+  }
+  if (b < nbuckets && j == 0) g1_store_jac(buckets, b, acc);
 }
 
-// step 4b: out[g] = sum of in[g * per_group .. (g + 1) * per_group), one workgroup per group
-__global__ __launch_bounds__(MSM_REDUCE_THREADS) void msm_reduce_kernel(const uint64_t* in, uint64_t per_group, uint64_t* out) {
-  __shared__ uint64_t lds[MSM_REDUCE_THREADS * 18];
-  const uint64_t base = (uint64_t)blockIdx.x * per_group;
+// step 4, one fold: in = 2^c points B_d, d = hi * cols + lo with cols = 2^floor(c/2), rows = 2^ceil(c/2);
+// out[k] = cols * (sum_lo B[k][lo]) + (k < cols ? sum_hi B[hi][k] : 0), k < rows, so that
+// sum_d d * B_d = sum_k k * out[k].  One workgroup per k: its first half sums row k, its second half column k.
+__global__ __launch_bounds__(MSM_FOLD_THREADS) void msm_fold_kernel(const uint64_t* in, int c, uint64_t* out) {
+  __shared__ uint64_t lds[MSM_FOLD_THREADS * 18];
+  const int lo_bits = c >> 1, hi_bits = c - lo_bits;
+  const uint32_t rows = 1u << hi_bits, cols = 1u << lo_bits, k = blockIdx.x;
+  const uint32_t t = threadIdx.x, u = t & 255;
   G1Jac acc = g1_inf();
-  for (uint64_t k = threadIdx.x; k < per_group; k += MSM_REDUCE_THREADS) acc = g1_add(acc, g1_load_jac(in, base + k));
-  g1_store_jac(lds, threadIdx.x, acc);
+  if (t < 256) { if (u < cols) acc = g1_load_jac(in, (uint64_t)k * cols + u); }
+  else if (k < cols && u < rows) acc = g1_load_jac(in, (uint64_t)u * cols + k);
+  g1_store_jac(lds, t, acc);
   __syncthreads();
-  for (int step = MSM_REDUCE_THREADS / 2; step >= 1; step >>= 1) {
-    if ((int)threadIdx.x < step) {
-      acc = g1_add(g1_load_jac(lds, threadIdx.x), g1_load_jac(lds, threadIdx.x + step));
-      g1_store_jac(lds, threadIdx.x, acc);
+  for (uint32_t step = 128; step >= 1; step >>= 1) {
+    if (u < step) {
+      acc = g1_add(g1_load_jac(lds, t), g1_load_jac(lds, t + step));
+      g1_store_jac(lds, t, acc);
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) g1_store_jac(out, blockIdx.x, acc);
+  if (t == 0) {
+    for (int d = 0; d < lo_bits; ++d) acc = g1_double(acc);
+    g1_store_jac(out, k, g1_add(acc, g1_load_jac(lds, 256)));
+  }
+}
+
+// Table set-up, one thread per base: table[w * nb + i] = 2^(c w) * P_i as affine points, w < windows.  The Jacobian
+// X, Y are parked in the table slot itself and Z in `zs`; the running products of the Z's in `prods` turn the W
+// conversions into one inversion per base.  (An infinite base gives W infinite entries; G1 has odd order, so
+// doubling a finite point never reaches infinity.)
+__global__ __launch_bounds__(256) void msm_table_kernel(const uint64_t* bases, uint64_t nb, int c, int windows, uint64_t* table,
+                                                        uint64_t* zs, uint64_t* prods) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nb) return;
+  const G1Affine a = g1_load_affine(bases, i);
+  if (g1_affine_is_inf(a)) {
+    G1Affine inf; inf.x = fq_zero(); inf.y = fq_zero();
+    for (int w = 0; w < windows; ++w) g1_store_affine(table, (uint64_t)w * nb + i, inf);
+    return;
+  }
+  G1Jac p = g1_from_affine(a);
+  Fq run = fq_one();
+  for (int w = 0; w < windows; ++w) {
+    if (w) for (int d = 0; d < c; ++d) p = g1_double(p);
+    const uint64_t slot = (uint64_t)w * nb + i;
+    fq_store(table, 2 * slot, p.x);
+    fq_store(table, 2 * slot + 1, p.y);
+    fq_store(zs, slot, p.z);
+    run = fq_mul(run, p.z);
+    fq_store(prods, slot, run);
+  }
+  Fq inv = fq_inverse(run);                       // 1 / (Z_0 ... Z_{W-1})
+  for (int w = windows - 1; w >= 0; --w) {
+    const uint64_t slot = (uint64_t)w * nb + i;
+    const Fq zi = w ? fq_mul(inv, fq_load(prods, slot - nb)) : inv;       // 1 / Z_w
+    inv = fq_mul(inv, fq_load(zs, slot));
+    const Fq zi2 = fq_sqr(zi);
+    fq_store(table, 2 * slot, fq_mul(fq_load(table, 2 * slot), zi2));
+    fq_store(table, 2 * slot + 1, fq_mul(fq_load(table, 2 * slot + 1), fq_mul(zi2, zi)));
+  }
 }
 
 // elementwise helpers for setting up and checking bases: out[i] = (first + i) * base (affine, via one inversion each)
