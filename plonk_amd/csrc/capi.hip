@@ -52,7 +52,7 @@ struct plk_ctx {
   std::map<std::string, DevBuf> ws;              // grow-only workspace slots
   struct PowTable { DevBuf lo, hi; size_t hi_count = 0; };
   std::map<std::array<uint64_t, 4>, PowTable> powers;   // g -> tables of g^j (coset transforms)
-  uint64_t* msm_table = nullptr;                 // affine G1 points 2^(c w) * base_i at [w * msm_nbases + i] (msm.cuh)
+  uint32_t* msm_table = nullptr;                 // affine G1 points 2^(c w) * base_i at [w * msm_nbases + i] (msm.cuh), 128 bytes each
   size_t msm_nbases = 0;
   int msm_c = 0;                                 // window width the table was built for
   size_t gp_rows = 0;                            // rows of the grand-product range held in the workspace
@@ -853,7 +853,7 @@ int msm_build_table(plk_ctx* ctx, hipStream_t s, const uint64_t* bases, size_t n
   const int c = msm_window_bits(nb), windows = (255 + c - 1) / c;
   const size_t slots = nb * (size_t)windows;
   uint64_t *zs = nullptr, *prods = nullptr;
-  HIP_TRY(ctx, hipMalloc((void**)&ctx->msm_table, slots * 96));
+  HIP_TRY(ctx, hipMalloc((void**)&ctx->msm_table, slots * A28_WORDS * 4));
   hipError_t e = hipMalloc((void**)&zs, slots * 48);
   if (e == hipSuccess) e = hipMalloc((void**)&prods, slots * 48);
   if (e == hipSuccess) {
@@ -884,9 +884,10 @@ int launch_msm(plk_ctx* ctx, hipStream_t s, const uint64_t* scalars, size_t n, u
   PairSort ps;
   if ((rc = pair_sort_alloc(ctx, s, "msm", total, &ps))) return rc;
   void *pf, *pb, *pa;
+  constexpr size_t point_bytes = J28_WORDS * 4;
   if ((rc = ws_get(ctx, "msm_bounds", 2 * nbuckets * 4, &pf))) return rc;
-  if ((rc = ws_get(ctx, "msm_buckets", nbuckets * 144, &pb))) return rc;
-  if ((rc = ws_get(ctx, "msm_fold", 2 * 256 * 144, &pa))) return rc;
+  if ((rc = ws_get(ctx, "msm_buckets", nbuckets * point_bytes, &pb))) return rc;
+  if ((rc = ws_get(ctx, "msm_fold", 2 * 256 * point_bytes + 2 * 144, &pa))) return rc;
   uint32_t* first = (uint32_t*)pf; uint32_t* last = first + nbuckets;
   HIP_TRY(ctx, hipMemsetAsync(pf, 0, 2 * nbuckets * 4, s));
   {
@@ -901,24 +902,25 @@ int launch_msm(plk_ctx* ctx, hipStream_t s, const uint64_t* scalars, size_t n, u
     hipLaunchKernelGGL(msm_bounds_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ps.pairs, (const uint64_t*)ps.or_bits, total, first, last);
   }
   {
-    ProfScope p(ctx, s, "msm_bucket_sum_kernel", 96.0 * (double)total);   // one affine table entry per pair
+    ProfScope p(ctx, s, "msm_bucket_sum_kernel", 128.0 * (double)total);   // one affine table entry per pair
     hipLaunchKernelGGL(msm_bucket_sum_kernel, dim3((unsigned)(((nbuckets << log_t) + 255) / 256)), dim3(256), 0, s, ps.pairs,
-                       (const uint64_t*)ps.or_bits, (const uint32_t*)first, (const uint32_t*)last, nbuckets, log_t, (const uint64_t*)ctx->msm_table,
-                       (uint64_t*)pb);
+                       (const uint64_t*)ps.or_bits, (const uint32_t*)first, (const uint32_t*)last, nbuckets, log_t, (const uint32_t*)ctx->msm_table,
+                       (uint32_t*)pb);
   }
   // folds: 2^c points -> 2^ceil(c/2) -> ... -> 2; then sum_d d * B_d = B_1
-  const uint64_t* in = (const uint64_t*)pb;
-  uint64_t* pp[2] = {(uint64_t*)pa, (uint64_t*)pa + 256 * 18};
+  const uint32_t* in = (const uint32_t*)pb;
+  uint32_t* pp[2] = {(uint32_t*)pa, (uint32_t*)pa + 256 * J28_WORDS};
+  uint64_t* last_two = (uint64_t*)((uint32_t*)pa + 2 * 256 * J28_WORDS);      // the last fold's two points in the ABI form
   int cc = c, flip = 0;
   while (cc > 1) {
     const int next = cc - (cc >> 1);
-    ProfScope p(ctx, s, "msm_fold_kernel", 144.0 * (double)(1ull << cc));
-    hipLaunchKernelGGL(msm_fold_kernel, dim3(1u << next), dim3(MSM_FOLD_THREADS), 0, s, in, cc, pp[flip]);
+    ProfScope p(ctx, s, "msm_fold_kernel", (double)point_bytes * (double)(1ull << cc));
+    hipLaunchKernelGGL(msm_fold_kernel, dim3(1u << next), dim3(MSM_FOLD_THREADS), 0, s, in, cc, pp[flip], next == 1 ? last_two : (uint64_t*)nullptr);
     in = pp[flip]; flip ^= 1; cc = next;
   }
   HIP_TRY(ctx, hipGetLastError());
   G1Jac sum;
-  HIP_TRY(ctx, hipMemcpyAsync(&sum, in + 18, 144, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipMemcpyAsync(&sum, last_two + 18, 144, hipMemcpyDeviceToHost, s));
   HIP_TRY(ctx, hipStreamSynchronize(s));
   const G1Affine r = g1_to_affine(sum);      // one base-field inversion, on the host
   for (int i = 0; i < 6; ++i) {

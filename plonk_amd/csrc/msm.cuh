@@ -17,6 +17,7 @@
 #pragma once
 #include "field.cuh"
 #include "g1.cuh"
+#include "fq28.cuh"
 #include "sigma_table.cuh"
 
 namespace plk {
@@ -64,72 +65,77 @@ __global__ __launch_bounds__(256) void msm_bounds_kernel(SigPairs pairs, const u
 
 // step 3: bucket b = sum of table[vals[p]] over its run; 2^log_t adjacent lanes share a bucket (entry j, j + 2^log_t, ...
 // each) and add their partial sums up by shuffles, so that long runs do not serialise on one lane
-__device__ __forceinline__ Fq fq_shfl_down(const Fq& a, int delta) {
-  Fq r;
+__device__ __forceinline__ F14 f14_shfl_down(const F14& a, int delta) {
+  F14 r;
 #pragma unroll
-  for (int k = 0; k < 12; ++k) r.l[k] = __shfl_down(a.l[k], delta);
+  for (int k = 0; k < 14; ++k) r.l[k] = __shfl_down(a.l[k], delta);
   return r;
 }
 
 __global__ __launch_bounds__(256) void msm_bucket_sum_kernel(SigPairs pairs, const uint64_t* or_bits, const uint32_t* first,
-                                                             const uint32_t* last, uint64_t nbuckets, int log_t, const uint64_t* table,
-                                                             uint64_t* buckets) {
+                                                             const uint32_t* last, uint64_t nbuckets, int log_t, const uint32_t* table,
+                                                             uint32_t* buckets) {
   const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   const uint64_t b = gid >> log_t;
   const uint32_t j = (uint32_t)gid & ((1u << log_t) - 1), t = 1u << log_t;
   const uint32_t* vals = pairs.vals[sig_buffer_before(or_bits, 8)];
-  G1Jac acc = g1_inf();
+  J28 acc = j28_inf();
   if (b < nbuckets) {
     const uint32_t end = last[b];
-    for (uint32_t p = first[b] + j; p < end; p += t) acc = g1_add_affine(acc, g1_load_affine(table, vals[p]));
+    for (uint32_t p = first[b] + j; p < end; p += t) acc = j28_add_affine(acc, a28_load(table, vals[p]));
   }
+  J28 part = acc;      // the full addition is a call taking references: only this copy lives in memory, not the loop's acc
   for (uint32_t step = t >> 1; step >= 1; step >>= 1) {      // whole waves get here: shuffles need every lane
-    G1Jac other;
-    other.x = fq_shfl_down(acc.x, step); other.y = fq_shfl_down(acc.y, step); other.z = fq_shfl_down(acc.z, step);
-    if (j + step >= t) other.z = fq_zero();                    // a lane of the next bucket: not ours
-    acc = g1_add(acc, other);
+    J28 other;
+    other.x = f14_shfl_down(part.x, step); other.y = f14_shfl_down(part.y, step); other.z = f14_shfl_down(part.z, step);
+    if (j + step >= t) other.z = f14_zero();                   // a lane of the next bucket: not ours
+    part = j28_add(part, other);
   }
-  if (b < nbuckets && j == 0) g1_store_jac(buckets, b, acc);
+  if (b < nbuckets && j == 0) j28_store(buckets, b, part);
 }
 
 // step 4, one fold: in = 2^c points B_d, d = hi * cols + lo with cols = 2^floor(c/2), rows = 2^ceil(c/2);
 // out[k] = cols * (sum_lo B[k][lo]) + (k < cols ? sum_hi B[hi][k] : 0), k < rows, so that
 // sum_d d * B_d = sum_k k * out[k].  One workgroup per k: its first half sums row k, its second half column k.
-__global__ __launch_bounds__(MSM_FOLD_THREADS) void msm_fold_kernel(const uint64_t* in, int c, uint64_t* out) {
-  __shared__ uint64_t lds[MSM_FOLD_THREADS * 18];
+// With abi_out set (the last fold) the points are also written there in the 12 x 32-bit form of g1.cuh.
+__global__ __launch_bounds__(MSM_FOLD_THREADS) void msm_fold_kernel(const uint32_t* in, int c, uint32_t* out, uint64_t* abi_out) {
+  __shared__ uint32_t lds[MSM_FOLD_THREADS * J28_WORDS];
   const int lo_bits = c >> 1, hi_bits = c - lo_bits;
   const uint32_t rows = 1u << hi_bits, cols = 1u << lo_bits, k = blockIdx.x;
   const uint32_t t = threadIdx.x, u = t & 255;
-  G1Jac acc = g1_inf();
-  if (t < 256) { if (u < cols) acc = g1_load_jac(in, (uint64_t)k * cols + u); }
-  else if (k < cols && u < rows) acc = g1_load_jac(in, (uint64_t)u * cols + k);
-  g1_store_jac(lds, t, acc);
+  J28 acc = j28_inf();
+  if (t < 256) { if (u < cols) acc = j28_load(in, (uint64_t)k * cols + u); }
+  else if (k < cols && u < rows) acc = j28_load(in, (uint64_t)u * cols + k);
+  j28_store(lds, t, acc);
   __syncthreads();
-  for (uint32_t step = 128; step >= 1; step >>= 1) {
+  for (uint32_t step = rows >> 1; step >= 1; step >>= 1) {      // rows >= cols: nothing lies beyond lane `rows` of a half
     if (u < step) {
-      acc = g1_add(g1_load_jac(lds, t), g1_load_jac(lds, t + step));
-      g1_store_jac(lds, t, acc);
+      acc = j28_add(j28_load(lds, t), j28_load(lds, t + step));
+      j28_store(lds, t, acc);
     }
     __syncthreads();
   }
   if (t == 0) {
-    for (int d = 0; d < lo_bits; ++d) acc = g1_double(acc);
-    g1_store_jac(out, k, g1_add(acc, g1_load_jac(lds, 256)));
+    for (int d = 0; d < lo_bits; ++d) acc = j28_double(acc);
+    acc = j28_add(acc, j28_load(lds, 256));
+    j28_store(out, k, acc);
+    if (abi_out) g1_store_jac(abi_out, k, j28_to_abi(acc));
   }
 }
 
-// Table set-up, one thread per base: table[w * nb + i] = 2^(c w) * P_i as affine points, w < windows.  The Jacobian
-// X, Y are parked in the table slot itself and Z in `zs`; the running products of the Z's in `prods` turn the W
-// conversions into one inversion per base.  (An infinite base gives W infinite entries; G1 has odd order, so
-// doubling a finite point never reaches infinity.)
-__global__ __launch_bounds__(256) void msm_table_kernel(const uint64_t* bases, uint64_t nb, int c, int windows, uint64_t* table,
+// Table set-up, one thread per base: table[w * nb + i] = 2^(c w) * P_i as affine points in the working form of
+// fq28.cuh (32 words each), w < windows.  Computed in the ABI form: the Jacobian X, Y are parked in the table slot
+// itself and Z in `zs`; the running products of the Z's in `prods` turn the W conversions to affine into one
+// inversion per base.  (An infinite base gives W infinite entries; G1 has odd order, so doubling a finite point
+// never reaches infinity.)
+__global__ __launch_bounds__(256) void msm_table_kernel(const uint64_t* bases, uint64_t nb, int c, int windows, uint32_t* table,
                                                         uint64_t* zs, uint64_t* prods) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= nb) return;
   const G1Affine a = g1_load_affine(bases, i);
   if (g1_affine_is_inf(a)) {
-    G1Affine inf; inf.x = fq_zero(); inf.y = fq_zero();
-    for (int w = 0; w < windows; ++w) g1_store_affine(table, (uint64_t)w * nb + i, inf);
+    A28 inf; inf.x = f14_zero(); inf.y = f14_zero();
+    for (int w = 0; w < windows; ++w) a28_store(table, (uint64_t)w * nb + i, inf);
     return;
   }
   G1Jac p = g1_from_affine(a);
@@ -137,8 +143,9 @@ __global__ __launch_bounds__(256) void msm_table_kernel(const uint64_t* bases, u
   for (int w = 0; w < windows; ++w) {
     if (w) for (int d = 0; d < c; ++d) p = g1_double(p);
     const uint64_t slot = (uint64_t)w * nb + i;
-    fq_store(table, 2 * slot, p.x);
-    fq_store(table, 2 * slot + 1, p.y);
+    uint64_t* park = reinterpret_cast<uint64_t*>(table + slot * A28_WORDS);     // 128 bytes: room for two 48-byte coordinates
+    fq_store(park, 0, p.x);
+    fq_store(park, 1, p.y);
     fq_store(zs, slot, p.z);
     run = fq_mul(run, p.z);
     fq_store(prods, slot, run);
@@ -149,8 +156,11 @@ __global__ __launch_bounds__(256) void msm_table_kernel(const uint64_t* bases, u
     const Fq zi = w ? fq_mul(inv, fq_load(prods, slot - nb)) : inv;       // 1 / Z_w
     inv = fq_mul(inv, fq_load(zs, slot));
     const Fq zi2 = fq_sqr(zi);
-    fq_store(table, 2 * slot, fq_mul(fq_load(table, 2 * slot), zi2));
-    fq_store(table, 2 * slot + 1, fq_mul(fq_load(table, 2 * slot + 1), fq_mul(zi2, zi)));
+    const uint64_t* park = reinterpret_cast<const uint64_t*>(table + slot * A28_WORDS);
+    G1Affine q;
+    q.x = fq_mul(fq_load(park, 0), zi2);
+    q.y = fq_mul(fq_load(park, 1), fq_mul(zi2, zi));
+    a28_store(table, slot, a28_from_abi(q));
   }
 }
 
