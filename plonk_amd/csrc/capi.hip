@@ -914,7 +914,7 @@ int launch_msm(plk_ctx* ctx, hipStream_t s, const uint64_t* scalars, size_t n, u
   int cc = c, flip = 0;
   while (cc > 1) {
     const int next = cc - (cc >> 1);
-    ProfScope p(ctx, s, "msm_fold_kernel", (double)point_bytes * (double)(1ull << cc));
+    ProfScope p(ctx, s, "msm_fold_kernel/c" + std::to_string(cc), (double)point_bytes * (double)(1ull << cc));
     hipLaunchKernelGGL(msm_fold_kernel, dim3(1u << next), dim3(MSM_FOLD_THREADS), 0, s, in, cc, pp[flip], next == 1 ? last_two : (uint64_t*)nullptr);
     in = pp[flip]; flip ^= 1; cc = next;
   }

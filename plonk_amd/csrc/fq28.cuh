@@ -99,7 +99,7 @@ __host__ __device__ __forceinline__ F14 mul28(const F14& a, const F14& b) {
   F14 r;
 #pragma unroll
   for (int k = 0; k < 14; ++k) {
-    uint64_t t = carry, u = 0;
+    uint64_t t = 0, u = carry;
 #pragma unroll
     for (int i = 0; i <= k; ++i) {      // the reduction terms newest m first: none of them is ready before this column
       t += (uint64_t)a.l[i] * b.l[k - i]; PLK_PIN28(t);
@@ -112,7 +112,7 @@ __host__ __device__ __forceinline__ F14 mul28(const F14& a, const F14& b) {
   }
 #pragma unroll
   for (int k = 14; k < 27; ++k) {
-    uint64_t t = carry, u = 0;
+    uint64_t t = 0, u = carry;
 #pragma unroll
     for (int i = k - 13; i <= 13; ++i) {
       t += (uint64_t)a.l[i] * b.l[k - i]; PLK_PIN28(t);
@@ -137,14 +137,14 @@ __host__ __device__ __forceinline__ F14 sqr28(const F14& a) {
   for (int i = 0; i < 14; ++i) a2.l[i] = a.l[i] << 1;
 #pragma unroll
   for (int k = 0; k < 14; ++k) {
-    uint64_t t = carry, u = 0;
+    uint64_t t = 0, u = carry;
 #pragma unroll
     for (int i = 0; i < k; ++i) {
       if (2 * i < k) { t += (uint64_t)a2.l[i] * a.l[k - i]; PLK_PIN28(t); }
       else if (2 * i == k) { t += (uint64_t)a.l[i] * a.l[i]; PLK_PIN28(t); }
       u += (uint64_t)m[k - 1 - i] * fq28c::Q[1 + i]; PLK_PIN28(u);
     }
-    if (k == 0) t += (uint64_t)a.l[0] * a.l[0];
+    if (k == 0) t = (uint64_t)a.l[0] * a.l[0];
     u += t;
     m[k] = ((uint32_t)u * fq28c::INV) & M28;
     u += (uint64_t)m[k] * fq28c::Q[0];
@@ -152,7 +152,7 @@ __host__ __device__ __forceinline__ F14 sqr28(const F14& a) {
   }
 #pragma unroll
   for (int k = 14; k < 27; ++k) {
-    uint64_t t = carry, u = 0;
+    uint64_t t = 0, u = carry;
 #pragma unroll
     for (int i = k - 13; i <= 13; ++i) {
       if (2 * i < k) { t += (uint64_t)a2.l[i] * a.l[k - i]; PLK_PIN28(t); }
@@ -253,7 +253,7 @@ __host__ __device__ __forceinline__ G1Jac j28_to_abi(const J28& p) {
 
 // 2 P on y^2 = x^3 + 4: A = X^2, B = Y^2, D = 4 X B, E = 3 A, X3 = E^2 - 2 D, Y3 = E (D - X3) - 8 B^2, Z3 = 2 Y Z
 // (dbl-2009-l with its squarings of sums turned into products, which keeps every value small): 4M + 3S
-__host__ __device__ __noinline__ J28 j28_double(const J28& p) {
+__host__ __device__ __forceinline__ J28 j28_double_inl(const J28& p) {
   if (j28_is_inf(p)) return p;
   const F14 A = sqr28(p.x), B = sqr28(p.y), B4 = f14_shl<2>(B);
   const F14 D = mul28(p.x, B4);
@@ -269,6 +269,8 @@ __host__ __device__ __noinline__ J28 j28_double(const J28& p) {
   f14_normalize(r.z);
   return r;
 }
+// the same as a call; the copy makes the callee read its argument from memory once instead of at every use
+__host__ __device__ __noinline__ J28 j28_double(const J28& p) { const J28 c = p; return j28_double_inl(c); }
 
 // P + Q, Q affine: madd-2007-bl, 7M + 4S
 __host__ __device__ __forceinline__ J28 j28_add_affine(const J28& p, const A28& q) {
@@ -295,7 +297,7 @@ __host__ __device__ __forceinline__ J28 j28_add_affine(const J28& p, const A28& 
 }
 
 // P + Q, both Jacobian: add-2007-bl, 11M + 5S
-__host__ __device__ __noinline__ J28 j28_add(const J28& p, const J28& q) {
+__host__ __device__ __forceinline__ J28 j28_add_inl(const J28& p, const J28& q) {
   if (j28_is_inf(p)) return q;
   if (j28_is_inf(q)) return p;
   const F14 Z1Z1 = sqr28(p.z), Z2Z2 = sqr28(q.z);
@@ -318,6 +320,7 @@ __host__ __device__ __noinline__ J28 j28_add(const J28& p, const J28& q) {
   r.z = mul28(f14_sub<2, 28>(f14_sub<2, 28>(sqr28(f14_add(p.z, q.z)), Z1Z1), Z2Z2), H);
   return r;
 }
+__host__ __device__ __noinline__ J28 j28_add(const J28& p, const J28& q) { const J28 a = p, b = q; return j28_add_inl(a, b); }
 
 __device__ __forceinline__ A28 a28_load(const uint32_t* base, size_t idx) {
   A28 p; p.x = f14_load(base, 2 * idx); p.y = f14_load(base, 2 * idx + 1); return p;

@@ -110,14 +110,14 @@ __global__ __launch_bounds__(MSM_FOLD_THREADS) void msm_fold_kernel(const uint32
   __syncthreads();
   for (uint32_t step = rows >> 1; step >= 1; step >>= 1) {      // rows >= cols: nothing lies beyond lane `rows` of a half
     if (u < step) {
-      acc = j28_add(j28_load(lds, t), j28_load(lds, t + step));
+      acc = j28_add_inl(acc, j28_load(lds, t + step));
       j28_store(lds, t, acc);
     }
     __syncthreads();
   }
   if (t == 0) {
-    for (int d = 0; d < lo_bits; ++d) acc = j28_double(acc);
-    acc = j28_add(acc, j28_load(lds, 256));
+    for (int d = 0; d < lo_bits; ++d) acc = j28_double_inl(acc);
+    acc = j28_add_inl(acc, j28_load(lds, 256));
     j28_store(out, k, acc);
     if (abi_out) g1_store_jac(abi_out, k, j28_to_abi(acc));
   }
