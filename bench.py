@@ -228,8 +228,9 @@ def other_workloads(args, prover, dist, rank, world):
                     terms_per_s=round(n / (ms * 1e-3), 1),
                     roofline={"bound": "hbm", "achieved": round(alg / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
-                              "note": "whole step; 128 algorithmic bytes per term; the work is ~190 base-field products per "
-                                      "term (one mixed addition per term and window), i.e. bound by integer multiply-add issue"},
+                              "note": "whole step; 128 algorithmic bytes per term; the work is ~180 base-field products per "
+                                      "term (one mixed addition per term and window over a precomputed table), i.e. bound "
+                                      "by integer multiply-add issue"},
                     kernels=[{"label": r["label"], "launches": r["launches"],
                               "ms_per_step": round(r["total_ms"] / (args.steps + args.warmup), 4)} for r in prof])
         if world == 1 and not args.no_cpu_baseline:

@@ -187,15 +187,18 @@ int plk_quotient(plk_ctx* ctx, const uint64_t* const* numerators, size_t count, 
  * points compute that sum.
  *  - A G1 point crosses the ABI in affine form as 12 uint64_t: x then y, each the memory of ark-ff
  *    `Fp384` (6 little-endian Montgomery limbs, R = 2^384); (0, 0) stands for the point at infinity.
- *  - plk_msm_set_bases copies n affine bases (the powers of tau) to the GPU once; they stay with the
- *    context.  plk_dev_msm_set_bases uses a caller-owned device table instead (not copied, not freed).
+ *  - plk_msm_set_bases takes n affine bases (the powers of tau) once and builds from them the table
+ *    2^(c w) * base_i (c ~ log2 n bits per window, ceil(255 / c) windows, 128 bytes per entry: 2.1 GB for 2^20
+ *    bases) that stays with the context; plk_dev_msm_set_bases does the same from a device array, which the
+ *    caller may free afterwards.  Both wait for the device.
  *  - plk_msm_g1 / plk_dev_msm_g1: scalars are n field elements in the usual form (Montgomery Fr), on the
  *    host / on the device; n must not exceed the number of bases.  The affine result is written to host
  *    memory; the call waits for the stream (the last ~300 point operations are serial and run on the host).
  *  - plk_dev_g1_multiples writes (first + i) * base, i < count, as affine points to device memory
  *    (test and benchmark set-up: a table whose discrete logarithms are known).
- * Run time depends on the scalars only through how evenly their 16-bit digits spread: one thread adds up
- * each bucket, so n equal scalars serialise. */
+ * The window width follows the number of BASES, so a call with far fewer scalars than bases is correct but
+ * slower than after a set_bases of that size.  Run time depends on the scalars only through how evenly their
+ * digits spread over the 2^c buckets: a few lanes add up each bucket, so n equal scalars serialise. */
 int plk_msm_set_bases(plk_ctx* ctx, const uint64_t* bases_host, size_t n);
 int plk_msm_g1(plk_ctx* ctx, const uint64_t* scalars_host, size_t n, uint64_t out_xy[12]);
 

@@ -877,9 +877,9 @@ int launch_msm(plk_ctx* ctx, hipStream_t s, const uint64_t* scalars, size_t n, u
   if (n == 0) return PLK_OK;
   const int c = ctx->msm_c, windows = (255 + c - 1) / c;
   const uint64_t total = (uint64_t)n * windows, nbuckets = 1ull << c;
-  // lanes per bucket: about 32 entries each (the lanes' partial sums cost log2(lanes) full additions to combine)
+  // lanes per bucket: 64 to 128 entries each (the lanes' partial sums cost log2(lanes) full additions to combine)
   int log_t = 0;
-  while (log_t < 6 && (total >> (c + log_t + 1)) >= 32) ++log_t;
+  while (log_t < 6 && (total >> (c + log_t + 1)) >= 64) ++log_t;
   int rc;
   PairSort ps;
   if ((rc = pair_sort_alloc(ctx, s, "msm", total, &ps))) return rc;

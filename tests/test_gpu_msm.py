@@ -54,7 +54,7 @@ def test_msm_vs_oracle_arbitrary_bases(ctx, n):
     assert limbs_to_point(got) == g1.msm(scalars, bases)
 
 
-@pytest.mark.parametrize("log_n", [9, 12, 15, 18, 20])
+@pytest.mark.parametrize("log_n", [5, 8, 9, 11, 12, 13, 15, 18, 20])   # window widths 5 ... 16, every fold shape
 def test_msm_closed_form(prover, log_n):
     """bases (i + 1) * G: the sum is (sum_i s_i (i + 1) mod r) * G, one scalar multiplication in the oracle.
     The sizes cross every window width the implementation picks (7, 10, 13, 16 bits)."""
