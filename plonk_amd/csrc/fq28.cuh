@@ -273,6 +273,9 @@ __host__ __device__ __forceinline__ J28 j28_double_inl(const J28& p) {
 __host__ __device__ __noinline__ J28 j28_double(const J28& p) { const J28 c = p; return j28_double_inl(c); }
 
 // P + Q, Q affine: madd-2007-bl, 7M + 4S
+// (INLINE_DOUBLING: the rare doubling branch is expanded in place instead of called, for kernels that must not
+// contain calls - a callee's register need counts for the whole kernel)
+template <bool INLINE_DOUBLING = false>
 __host__ __device__ __forceinline__ J28 j28_add_affine(const J28& p, const A28& q) {
   if (a28_is_inf(q)) return p;
   if (j28_is_inf(p)) return j28_from_affine(q);
@@ -282,6 +285,7 @@ __host__ __device__ __forceinline__ J28 j28_add_affine(const J28& p, const A28& 
   f14_normalize(rr);
   if (f14_product_is_zero(HH)) {               // Q = +-P.  (The copy keeps p itself out of memory: j28_double is a call.)
     if (!f14_product_is_zero(mul28(rr, f14_one()))) return j28_inf();
+    if (INLINE_DOUBLING) return j28_double_inl(p);
     const J28 copy = p;
     return j28_double(copy);
   }

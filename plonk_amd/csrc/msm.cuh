@@ -64,7 +64,8 @@ __global__ __launch_bounds__(256) void msm_bounds_kernel(SigPairs pairs, const u
 }
 
 // step 3: bucket b = sum of table[vals[p]] over its run; 2^log_t adjacent lanes share a bucket (entry j, j + 2^log_t, ...
-// each) and add their partial sums up by shuffles, so that long runs do not serialise on one lane
+// each), so that long runs do not serialise on one lane, and a second kernel adds their partial sums up.  (Two kernels
+// because the mixed addition alone fits three waves per SIMD; with the full addition beside it two.)
 __device__ __forceinline__ F14 f14_shfl_down(const F14& a, int delta) {
   F14 r;
 #pragma unroll
@@ -72,26 +73,37 @@ __device__ __forceinline__ F14 f14_shfl_down(const F14& a, int delta) {
   return r;
 }
 
-__global__ __launch_bounds__(256) void msm_bucket_sum_kernel(SigPairs pairs, const uint64_t* or_bits, const uint32_t* first,
-                                                             const uint32_t* last, uint64_t nbuckets, int log_t, const uint32_t* table,
-                                                             uint32_t* buckets) {
+__global__ __launch_bounds__(256, 3) void msm_bucket_sum_kernel(SigPairs pairs, const uint64_t* or_bits, const uint32_t* first,
+                                                                const uint32_t* last, uint64_t nbuckets, int log_t, const uint32_t* table,
+                                                                uint32_t* partials) {
   const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   const uint64_t b = gid >> log_t;
+  if (b >= nbuckets) return;
   const uint32_t j = (uint32_t)gid & ((1u << log_t) - 1), t = 1u << log_t;
   const uint32_t* vals = pairs.vals[sig_buffer_before(or_bits, 8)];
   J28 acc = j28_inf();
+  const uint32_t end = last[b];
+  for (uint32_t p = first[b] + j; p < end; p += t) acc = j28_add_affine<true>(acc, a28_load(table, vals[p]));
+  j28_store(partials, gid, acc);
+}
+
+// bucket b = sum of its 2^log_t >= 2 partial sums: two lanes per bucket add up half of them each, one after the
+// other, and combine by a shuffle (a tree over all the lanes would leave most of them adding nothing)
+__global__ __launch_bounds__(256) void msm_bucket_combine_kernel(const uint32_t* partials, uint64_t nbuckets, int log_t, uint32_t* buckets) {
+  const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;      // the grid covers whole waves: the shuffle needs every lane
+  const uint64_t b = gid >> 1;
+  const uint32_t h = (uint32_t)gid & 1, per = 1u << (log_t - 1);
+  J28 part = j28_inf();
   if (b < nbuckets) {
-    const uint32_t end = last[b];
-    for (uint32_t p = first[b] + j; p < end; p += t) acc = j28_add_affine(acc, a28_load(table, vals[p]));
+    const uint64_t at = (b << log_t) + (uint64_t)h * per;
+    part = j28_load(partials, at);
+    for (uint32_t k = 1; k < per; ++k) part = j28_add_inl(part, j28_load(partials, at + k));
   }
-  J28 part = acc;      // the full addition is a call taking references: only this copy lives in memory, not the loop's acc
-  for (uint32_t step = t >> 1; step >= 1; step >>= 1) {      // whole waves get here: shuffles need every lane
-    J28 other;
-    other.x = f14_shfl_down(part.x, step); other.y = f14_shfl_down(part.y, step); other.z = f14_shfl_down(part.z, step);
-    if (j + step >= t) other.z = f14_zero();                   // a lane of the next bucket: not ours
-    part = j28_add(part, other);
-  }
-  if (b < nbuckets && j == 0) j28_store(buckets, b, part);
+  J28 other;
+  other.x = f14_shfl_down(part.x, 1); other.y = f14_shfl_down(part.y, 1); other.z = f14_shfl_down(part.z, 1);
+  if (h) other.z = f14_zero();
+  part = j28_add_inl(part, other);
+  if (b < nbuckets && h == 0) j28_store(buckets, b, part);
 }
 
 // step 4, one fold: in = 2^c points B_d, d = hi * cols + lo with cols = 2^floor(c/2), rows = 2^ceil(c/2);
