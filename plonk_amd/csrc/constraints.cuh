@@ -8,6 +8,7 @@
 // One thread per point; every column is read once (plus the neighbouring z).
 #pragma once
 #include "field.cuh"
+#include "fr29.cuh"
 
 namespace plk {
 
@@ -18,26 +19,38 @@ struct GateCols {
   const uint64_t* s[9];  // selector evaluations in ASTKind order (src/ast.rs:56-66); nullptr = absent
 };
 
+// The arithmetic of both kernels runs on 29-bit limbs (fr29.cuh): columns are cut into limbs once, sums and
+// differences are limb-wise and lazy, products are mont256, and one full reduction at the end gives the canonical
+// element the reference's field arithmetic would.  Values stay far below the 32 p that reduction accepts (the
+// bounds are beside each line, in units of p; inputs are canonical, below p).
+__device__ __forceinline__ F9 f9_load(const uint64_t* col, uint64_t i) { return f9_from_fe(fe_load(col, i)); }
+
+__device__ __forceinline__ Fe gate_point(const F9& a, const F9& b, const F9& c, const F9& o, const uint64_t* const s[9], uint64_t i) {
+  const F9 one = f9_from_fe(fe_one());
+  F9 acc;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) acc.l[k] = 0;
+  // Int (0) and Bool (1) contribute F::zero() (:396-397)
+  if (s[2]) acc = f9_add(acc, mont256(f9_sub_q4(o, f9_add(a, b)), f9_load(s[2], i)));                   // Add  :400   o-(a+b) < 5, term < 3.3
+  if (s[3]) acc = f9_add(acc, mont256(f9_add(f9_sub_q2(o, a), b), f9_load(s[3], i)));                   // Sub  :403   o-a+b < 4, term < 2.9
+  if (s[4] || s[8]) {
+    const F9 ab = mont256(a, b);                                                                        // < 1.46
+    if (s[4]) acc = f9_add(acc, mont256(f9_sub_q2(o, ab), f9_load(s[4], i)));                           // Mult :406   < 3, term < 2.4
+    if (s[8]) {                                                                                         // If   :419-423
+      const F9 t = mont256(f9_sub_q2(one, a), c);                                                       // (1-a) c < 2.4
+      acc = f9_add(acc, mont256(f9_sub_q4(o, f9_add(ab, t)), f9_load(s[8], i)));                        // ab + t < 3.9; < 5, term < 3.3
+    }
+  }
+  if (s[5]) acc = f9_add(acc, mont256(f9_sub_q2(mont256(o, b), a), f9_load(s[5], i)));                  // Div  :409   o b - a < 3.5, term < 2.6
+  if (s[6]) acc = f9_add(acc, mont256(mont256(f9_sub_q2(a, b), o), f9_load(s[6], i)));                  // Eq   :412   (a-b) o < 2.4, term < 2.1
+  if (s[7]) acc = f9_add(acc, mont256(f9_add(o, f9_sub_q2(a, one)), f9_load(s[7], i)));                 // Not  :415   o+a-1 < 4, term < 2.9
+  return fe_reduce_f9(acc);       // seven terms: limbs below 7 * 2^29, value below 20 p
+}
+
 __global__ __launch_bounds__(EW_THREADS) void gate_constraint_kernel(GateCols cols, uint64_t N, uint64_t* out) {
   const uint64_t i = (uint64_t)blockIdx.x * EW_THREADS + threadIdx.x;
   if (i >= N) return;
-  const Fe a = fe_load(cols.w[0], i), b = fe_load(cols.w[1], i), c = fe_load(cols.w[2], i), o = fe_load(cols.w[3], i);
-  Fe acc = fe_zero();
-  // Int (0) and Bool (1) contribute F::zero() (:396-397)
-  if (cols.s[2]) acc = fe_add(acc, fe_mul(fe_load(cols.s[2], i), fe_sub(o, fe_add(a, b))));          // Add  :400
-  if (cols.s[3]) acc = fe_add(acc, fe_mul(fe_load(cols.s[3], i), fe_sub(o, fe_sub(a, b))));          // Sub  :403
-  if (cols.s[4] || cols.s[8]) {
-    const Fe ab = fe_mul(a, b);
-    if (cols.s[4]) acc = fe_add(acc, fe_mul(fe_load(cols.s[4], i), fe_sub(o, ab)));                  // Mult :406
-    if (cols.s[8]) {                                                                                 // If   :419-423
-      const Fe one_minus_a = fe_sub(fe_one(), a);
-      acc = fe_add(acc, fe_mul(fe_load(cols.s[8], i), fe_sub(o, fe_add(ab, fe_mul(one_minus_a, c)))));
-    }
-  }
-  if (cols.s[5]) acc = fe_add(acc, fe_mul(fe_load(cols.s[5], i), fe_sub(fe_mul(o, b), a)));          // Div  :409
-  if (cols.s[6]) acc = fe_add(acc, fe_mul(fe_load(cols.s[6], i), fe_mul(o, fe_sub(a, b))));          // Eq   :412
-  if (cols.s[7]) acc = fe_add(acc, fe_mul(fe_load(cols.s[7], i), fe_sub(fe_add(o, a), fe_one())));   // Not  :415
-  fe_store(out, i, acc);
+  fe_store(out, i, gate_point(f9_load(cols.w[0], i), f9_load(cols.w[1], i), f9_load(cols.w[2], i), f9_load(cols.w[3], i), cols.s, i));
 }
 
 // The same sums for a 4n-point domain held coset-major: plane r (r = 0..3) of a column holds its
@@ -48,24 +61,6 @@ struct GateColsCoset {
   const uint64_t* w0[4];  const uint64_t* s0[9];   // plane 0
   const uint64_t* w[4];   const uint64_t* s[9];    // planes 1..3 at + (r - 1) * n elements
 };
-
-__device__ __forceinline__ Fe gate_point(const Fe& a, const Fe& b, const Fe& c, const Fe& o, const uint64_t* const s[9], uint64_t i) {
-  Fe acc = fe_zero();
-  if (s[2]) acc = fe_add(acc, fe_mul(fe_load(s[2], i), fe_sub(o, fe_add(a, b))));          // Add  :400
-  if (s[3]) acc = fe_add(acc, fe_mul(fe_load(s[3], i), fe_sub(o, fe_sub(a, b))));          // Sub  :403
-  if (s[4] || s[8]) {
-    const Fe ab = fe_mul(a, b);
-    if (s[4]) acc = fe_add(acc, fe_mul(fe_load(s[4], i), fe_sub(o, ab)));                  // Mult :406
-    if (s[8]) {                                                                            // If   :419-423
-      const Fe one_minus_a = fe_sub(fe_one(), a);
-      acc = fe_add(acc, fe_mul(fe_load(s[8], i), fe_sub(o, fe_add(ab, fe_mul(one_minus_a, c)))));
-    }
-  }
-  if (s[5]) acc = fe_add(acc, fe_mul(fe_load(s[5], i), fe_sub(fe_mul(o, b), a)));          // Div  :409
-  if (s[6]) acc = fe_add(acc, fe_mul(fe_load(s[6], i), fe_mul(o, fe_sub(a, b))));          // Eq   :412
-  if (s[7]) acc = fe_add(acc, fe_mul(fe_load(s[7], i), fe_sub(fe_add(o, a), fe_one())));   // Not  :415
-  return acc;
-}
 
 // One thread per point i = 4k + r: lanes 4j..4j+3 share k and differ in the plane, so every plane
 // is read in runs of 16 consecutive elements per wave and the output store is fully coalesced.
@@ -78,10 +73,37 @@ __global__ __launch_bounds__(EW_THREADS) void gate_constraint_coset_kernel(GateC
   const uint64_t* s[9];
 #pragma unroll
   for (int j = 0; j < 9; ++j) s[j] = r ? (cols.s[j] ? cols.s[j] + off : nullptr) : cols.s0[j];
-  const Fe a = fe_load(r ? cols.w[0] + off : cols.w0[0], k), b = fe_load(r ? cols.w[1] + off : cols.w0[1], k);
-  const Fe c = fe_load(r ? cols.w[2] + off : cols.w0[2], k), o = fe_load(r ? cols.w[3] + off : cols.w0[3], k);
+  const F9 a = f9_load(r ? cols.w[0] + off : cols.w0[0], k), b = f9_load(r ? cols.w[1] + off : cols.w0[1], k);
+  const F9 c = f9_load(r ? cols.w[2] + off : cols.w0[2], k), o = f9_load(r ? cols.w[3] + off : cols.w0[3], k);
   fe_store(out, i, gate_point(a, b, c, o, s, k));
 }
+
+// E_i of one point on 29-bit limbs, as gate_point: lhs = prod (w + beta i + gamma), rhs = prod (w + beta sigma + gamma),
+// E = z_next lhs - z_cur rhs.  Bounds in units of p beside each line.
+__host__ __device__ __forceinline__ F9 f9_from_u64(uint64_t v) {
+  F9 r;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) r.l[k] = 0;
+  r.l[0] = (uint32_t)v & M29; r.l[1] = (uint32_t)(v >> 29) & M29; r.l[2] = (uint32_t)(v >> 58);
+  return r;
+}
+struct PermPoint {
+  F9 bi_g, gamma, lhs, rhs;
+  __host__ __device__ __forceinline__ PermPoint(uint64_t index, const Fe& beta_r2, const Fe& g) {
+    gamma = f9_from_fe(g);
+    bi_g = f9_add(mont256(f9_from_u64(index), f9_from_fe(beta_r2)), gamma);     // beta * F::from(i) + gamma (:351)   < 2.5
+  }
+  // x * y = beta * sigma(point), whichever of the two carries the conversion factor
+  __host__ __device__ __forceinline__ void wire(int j, const F9& w, const F9& x, const F9& y) {
+    F9 tl = f9_add(w, bi_g);                                  // < 3.5, limbs < 3 * 2^29
+    F9 tr = f9_add(f9_add(w, mont256(x, y)), gamma);          // < 3.5
+    if (j == 0) { f9_normalize(tl); f9_normalize(tr); lhs = tl; rhs = tr; }
+    else { lhs = mont256(tl, lhs); rhs = mont256(tr, rhs); }   // < 6.5, 11.2, 18.5
+  }
+  __host__ __device__ __forceinline__ Fe finish(const F9& z_next, const F9& z_cur) const {
+    return fe_reduce_f9(f9_sub_k<16>(mont256(lhs, z_next), mont256(rhs, z_cur)));   // each < 9.4; difference + 16 p < 26
+  }
+};
 
 struct PermColsCoset {
   const uint64_t* z0;  const uint64_t* sig0[4];  const uint64_t* w0[4];   // plane 0: z[0..n), RAW u64 sigma indices, wire table
@@ -99,25 +121,20 @@ __global__ __launch_bounds__(EW_THREADS) void perm_constraint_coset_kernel(PermC
   if (inext >= N) inext -= N;
   const uint64_t rn = inext & 3, kn = inext >> 2;
   const uint64_t off = r ? (uint64_t)(r - 1) * n * 4 : 0;
-  const Fe z_cur = fe_load(r ? cols.z + off : cols.z0, k);
-  const Fe z_next = fe_load(rn ? cols.z + (rn - 1) * n * 4 : cols.z0, kn);
-  Fe iraw = fe_zero(); iraw.l[0] = (uint32_t)i; iraw.l[1] = (uint32_t)(i >> 32);
-  const Fe bi_g = fe_add(fe_mul(iraw, beta_r2), gamma);   // beta * F::from(i) + gamma  (:351)
-  Fe lhs, rhs;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const Fe w = fe_load(r ? cols.w[j] + off : cols.w0[j], k);
-    // on the trace domain sigma_j(omega^k) IS F::from(sigma_j[k]): the raw index times beta * R^2;
-    // elsewhere the evaluated sigma polynomial times beta.  One multiplication either way.
-    Fe x, y;
-    if (r) { x = fe_load(cols.sig[j] + off, k); y = beta; }
-    else { const uint64_t sv = cols.sig0[j][k]; x = fe_zero(); x.l[0] = (uint32_t)sv; x.l[1] = (uint32_t)(sv >> 32); y = beta_r2; }
-    const Fe tl = fe_add(w, bi_g);
-    const Fe tr = fe_add(fe_add(w, fe_mul(x, y)), gamma);
-    lhs = (j == 0) ? tl : fe_mul(lhs, tl);
-    rhs = (j == 0) ? tr : fe_mul(rhs, tr);
-  }
-  fe_store(out, i, fe_sub(fe_mul(z_next, lhs), fe_mul(z_cur, rhs)));
+  PermPoint pt(i, beta_r2, gamma);
+  // on the trace domain sigma_j(omega^k) IS F::from(sigma_j[k]): the raw index times beta * R^2;
+  // elsewhere the evaluated sigma polynomial times beta.  One multiplication either way.
+  const F9 y = f9_from_fe(r ? beta : beta_r2);
+  auto wire = [&](int j) {          // called four times in so many words: the loop form is not unrolled (the products hold asm statements)
+    const F9 w = f9_load(r ? cols.w[j] + off : cols.w0[j], k);
+    F9 x;
+    if (r) x = f9_load(cols.sig[j] + off, k);
+    else x = f9_from_u64(cols.sig0[j][k]);
+    pt.wire(j, w, x, y);
+  };
+  wire(0); wire(1); wire(2); wire(3);
+  // (z is read last: fewer values are alive across the products above)
+  fe_store(out, i, pt.finish(f9_load(rn ? cols.z + (rn - 1) * n * 4 : cols.z0, kn), f9_load(r ? cols.z + off : cols.z0, k)));
 }
 
 struct PermCols {
@@ -135,19 +152,13 @@ __global__ __launch_bounds__(EW_THREADS) void perm_constraint_kernel(PermCols co
   uint64_t inext = i + z_shift;            // z_shift < z_len is checked on the host
   if (inext >= z_len) inext -= z_len;
   const uint64_t gi = index0 + i;
-  Fe iraw = fe_zero(); iraw.l[0] = (uint32_t)gi; iraw.l[1] = (uint32_t)(gi >> 32);
-  const Fe bi_g = fe_add(fe_mul(iraw, beta_r2), gamma);   // beta * F::from(i) + gamma  (:351)
-  Fe lhs, rhs;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const Fe w = fe_load(cols.w[k], i);
-    const Fe tl = fe_add(w, bi_g);                                                   // :354-358
-    const Fe tr = fe_add(fe_add(w, fe_mul(beta, fe_load(cols.s[k], i))), gamma);    // :365-369
-    lhs = (k == 0) ? tl : fe_mul(lhs, tl);
-    rhs = (k == 0) ? tr : fe_mul(rhs, tr);
-  }
-  const Fe e = fe_sub(fe_mul(fe_load(cols.z, inext), lhs), fe_mul(fe_load(cols.z, i), rhs));   // :372
-  fe_store(out, i, e);
+  PermPoint pt(gi, beta_r2, gamma);
+  const F9 beta9 = f9_from_fe(beta);
+  pt.wire(0, f9_load(cols.w[0], i), f9_load(cols.s[0], i), beta9);   // :354-369 (in so many words: the loop form is not unrolled)
+  pt.wire(1, f9_load(cols.w[1], i), f9_load(cols.s[1], i), beta9);
+  pt.wire(2, f9_load(cols.w[2], i), f9_load(cols.s[2], i), beta9);
+  pt.wire(3, f9_load(cols.w[3], i), f9_load(cols.s[3], i), beta9);
+  fe_store(out, i, pt.finish(f9_load(cols.z, inext), f9_load(cols.z, i)));                                 // :372
 }
 
 // Natural-order evaluations on the 4n-point domain from the four coset tables of a column:

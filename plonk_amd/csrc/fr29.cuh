@@ -195,7 +195,61 @@ __device__ __forceinline__ void mont29_x2(const F9& a1, const F9& b1, const F9& 
 }
 #undef PLK_PIN
 
-__device__ __forceinline__ F9 f9_add(const F9& a, const F9& b) {
+// a * b * 2^-256 mod p: the library's own Montgomery product on 29-bit limbs, for point-wise kernels whose two
+// operands are both data.  Eight columns are reduced as in mont29; of the ninth only the low 24 bits are
+// cleared (8 * 29 + 24 = 256), and the columns above it are re-cut 24 bits higher.
+// Input: a lazy (limbs < 1.3 * 2^31, value V_a p), b normalised (value V_b p).  Output: normalised, value
+// below (0.4527 V_a V_b + 1) p  (p / 2^256 < 0.4527).
+__host__ __device__ __forceinline__ F9 mont256(const F9& a_in, const F9& b_in) {
+  F9 a = a_in, b = b_in;
+#ifdef __HIP_DEVICE_COMPILE__
+  // The compiler must not know how many bits a limb has: when both factors of a partial product are known to fit
+  // 24 bits (the top limbs of freshly cut operands, m[8]) it selects 24-bit multiplies and the result's top limb
+  // comes out wrong (seen with ROCm 7.2's clang on gfx950; the same source is right on the host and when the
+  // operands come from memory).  The empty asm statements hide the ranges and emit nothing.
+#pragma unroll
+  for (int i = 0; i < 9; ++i) asm volatile("" : "+v"(a.l[i]), "+v"(b.l[i]));
+#endif
+  uint64_t acc = M29;
+  uint32_t m[9], c[10];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+#pragma unroll
+    for (int i = 0; i <= k; ++i) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+    for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * f9c::kp_limb29(1, k - i);
+    m[k] = ~(uint32_t)acc & M29;
+    acc = (acc >> 29) + (k < 7 ? (uint64_t)M29 : 0);
+  }
+#pragma unroll
+  for (int i = 0; i <= 8; ++i) acc += (uint64_t)a.l[i] * b.l[8 - i];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc += (uint64_t)m[i] * f9c::kp_limb29(1, 8 - i);
+  m[8] = (0u - (uint32_t)acc) & ((1u << 24) - 1);
+  acc += m[8];                                   // the p[0] = 1 term: the low 24 bits are now zero
+#ifdef __HIP_DEVICE_COMPILE__
+  asm volatile("" : "+v"(m[8]));
+#endif
+  c[0] = (uint32_t)acc & M29;
+  acc >>= 29;
+#pragma unroll
+  for (int k = 9; k < 17; ++k) {
+#pragma unroll
+    for (int i = k - 8; i <= 8; ++i) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+    for (int i = k - 8; i <= 8; ++i) acc += (uint64_t)m[i] * f9c::kp_limb29(1, k - i);
+    c[k - 8] = (uint32_t)acc & M29;
+    acc >>= 29;
+  }
+  c[9] = (uint32_t)acc;
+  F9 r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.l[i] = ((c[i] >> 24) | (c[i + 1] << 5)) & M29;
+  r.l[8] = (c[8] >> 24) | (c[9] << 5);
+  return r;
+}
+
+__host__ __device__ __forceinline__ F9 f9_add(const F9& a, const F9& b) {
   F9 r;
 #pragma unroll
   for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] + b.l[i];
@@ -203,7 +257,7 @@ __device__ __forceinline__ F9 f9_add(const F9& a, const F9& b) {
 }
 
 // a - t + 2p, limb-wise; t normalised with value < 2p
-__device__ __forceinline__ F9 f9_sub_q2(const F9& a, const F9& t) {
+__host__ __device__ __forceinline__ F9 f9_sub_q2(const F9& a, const F9& t) {
   F9 r;
 #pragma unroll
   for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] + (f9c::q2_limb(i) - t.l[i]);
@@ -211,10 +265,20 @@ __device__ __forceinline__ F9 f9_sub_q2(const F9& a, const F9& t) {
 }
 
 // a - t + 4p, limb-wise; t = sum of two normalised values (limbs <= 2^30 - 2, value < 4p - 2^233)
-__device__ __forceinline__ F9 f9_sub_q4(const F9& a, const F9& t) {
+__host__ __device__ __forceinline__ F9 f9_sub_q4(const F9& a, const F9& t) {
   F9 r;
 #pragma unroll
   for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] + (f9c::q4_limb(i) - t.l[i]);
+  return r;
+}
+
+// a - t + K p, limb-wise; t normalised with value <= (K - 1) p
+template <int K>
+__host__ __device__ __forceinline__ F9 f9_sub_k(const F9& a, const F9& t) {
+  F9 r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i)
+    r.l[i] = a.l[i] + ((i == 0 ? f9c::kp_limb29(K, 0) + (1u << 29) : (i < 8 ? f9c::kp_limb29(K, i) + (1u << 29) - 1 : f9c::kp_limb29(K, 8) - 1)) - t.l[i]);
   return r;
 }
 
