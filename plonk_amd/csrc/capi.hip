@@ -762,7 +762,7 @@ struct PairSort {
   uint64_t entries, total;
 };
 
-int pair_sort_alloc(plk_ctx* ctx, hipStream_t s, const std::string& prefix, uint64_t total, PairSort* ps) {
+int pair_sort_alloc(plk_ctx* ctx, hipStream_t s, const std::string& prefix, uint64_t total, PairSort* ps, bool with_vals = true) {
   ps->total = total;
   ps->waves = (uint32_t)((total + SIG_CHUNK - 1) / SIG_CHUNK);
   ps->entries = (uint64_t)SIG_BINS * ps->waves;
@@ -770,10 +770,11 @@ int pair_sort_alloc(plk_ctx* ctx, hipStream_t s, const std::string& prefix, uint
   int rc;
   void *pk, *pv, *ph;
   if ((rc = ws_get(ctx, prefix + "_keys", 2 * total * 8, &pk))) return rc;
-  if ((rc = ws_get(ctx, prefix + "_vals", 2 * total * 4, &pv))) return rc;
+  pv = nullptr;
+  if (with_vals && (rc = ws_get(ctx, prefix + "_vals", 2 * total * 4, &pv))) return rc;
   if ((rc = ws_get(ctx, prefix + "_hist", 8 + (ps->entries + ps->scan_tiles) * 4, &ph))) return rc;
   ps->pairs.keys[0] = (uint64_t*)pk; ps->pairs.keys[1] = (uint64_t*)pk + total;
-  ps->pairs.vals[0] = (uint32_t*)pv; ps->pairs.vals[1] = (uint32_t*)pv + total;
+  ps->pairs.vals[0] = (uint32_t*)pv; ps->pairs.vals[1] = pv ? (uint32_t*)pv + total : nullptr;
   ps->or_bits = (uint64_t*)ph;             // 8-byte aligned head of the slot
   ps->hist = (uint32_t*)((char*)ph + 8);
   ps->sums = ps->hist + ps->entries;
@@ -882,7 +883,7 @@ int launch_msm(plk_ctx* ctx, hipStream_t s, const uint64_t* scalars, size_t n, u
   while (log_t < 6 && (total >> (c + log_t + 1)) >= 32) ++log_t;
   int rc;
   PairSort ps;
-  if ((rc = pair_sort_alloc(ctx, s, "msm", total, &ps))) return rc;
+  if ((rc = pair_sort_alloc(ctx, s, "msm", total, &ps, false))) return rc;     // the keys carry the table index
   void *pf, *pb, *pa;
   constexpr size_t point_bytes = J28_WORDS * 4;
   if ((rc = ws_get(ctx, "msm_bounds", 2 * nbuckets * 4, &pf))) return rc;
@@ -895,7 +896,7 @@ int launch_msm(plk_ctx* ctx, hipStream_t s, const uint64_t* scalars, size_t n, u
   {
     ProfScope p(ctx, s, "msm_digits_kernel", 32.0 * (double)n);
     hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scalars, (uint64_t)n, (uint64_t)ctx->msm_nbases, c,
-                       windows, ps.pairs.keys[0], ps.pairs.vals[0], ps.or_bits);
+                       windows, ps.pairs.keys[0], ps.or_bits);
     HIP_TRY(ctx, hipGetLastError());
   }
   if ((rc = pair_sort_run(ctx, s, ps, 0.0))) return rc;

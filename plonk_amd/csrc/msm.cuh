@@ -6,8 +6,8 @@
 // T[w][i] = 2^(c w) * P_i (affine, W = ceil(255 / c) windows) is built once; with it digit d of window w of
 // scalar i contributes d * T[w][i], and ALL windows share one set of 2^c buckets:
 //   1. every scalar (Montgomery form, as ark-ff keeps it) is made canonical and cut into W digits of c bits;
-//      digit d != 0 of window w gives the pair (key = d, value = w * nb + i);
-//   2. the pairs are sorted by key (the stable radix sort of sigma_table.cuh);
+//      digit d of window w gives the 64-bit key (w * nb + i) << 16 | d;
+//   2. the keys are sorted by digit (the stable radix sort of sigma_table.cuh, two byte passes);
 //   3. a fixed number of adjacent lanes per bucket add up its run of table entries (mixed additions) and
 //      combine their partial sums through lane shuffles;
 //   4. sum_d d * B_d by folding: with d = hi * 2^h + lo, sum_d d B_d = sum_k k (2^h R_k + C_k), R_k / C_k the
@@ -25,10 +25,13 @@ namespace plk {
 constexpr int MSM_FOLD_THREADS = 512;
 constexpr int MSM_MAX_WINDOW_BITS = 16;   // a fold handles a matrix of at most 256 x 256 buckets
 
-// step 1: keys[w * n + i] = digit w of scalar i, vals[w * n + i] = its table entry w * nb + i; also the OR of all
-// keys (for the sort)
+constexpr int MSM_KEY_DIGIT_BITS = 16;    // a pair is one 64-bit key: (table entry << 16) | digit; the sort looks at the digit only
+static_assert(MSM_MAX_WINDOW_BITS <= MSM_KEY_DIGIT_BITS, "a digit must fit the low bits of a key");
+
+// step 1: key[w * n + i] = (table entry w * nb + i) << 16 | digit w of scalar i; also the OR of all digits (the sort
+// skips the byte passes it shows to be zero, which leaves the upper bits in their stable order)
 __global__ __launch_bounds__(256) void msm_digits_kernel(const uint64_t* scalars, uint64_t n, uint64_t nb, int c, int windows,
-                                                         uint64_t* keys, uint32_t* vals, uint64_t* or_bits) {
+                                                         uint64_t* keys, uint64_t* or_bits) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   uint64_t seen = 0;
   if (i < n) {
@@ -39,10 +42,8 @@ __global__ __launch_bounds__(256) void msm_digits_kernel(const uint64_t* scalars
       uint64_t chunk = s.l[limb];
       if (limb + 1 < 8) chunk |= (uint64_t)s.l[limb + 1] << 32;
       const uint64_t d = (chunk >> off) & ((1ull << c) - 1);
-      const uint64_t key = d ? d : SIG_NO_WIRE;
-      keys[(uint64_t)w * n + i] = key;
-      vals[(uint64_t)w * n + i] = (uint32_t)((uint64_t)w * nb + i);
-      if (d) seen |= key;
+      keys[(uint64_t)w * n + i] = (((uint64_t)w * nb + i) << MSM_KEY_DIGIT_BITS) | d;    // digit 0 lands in bucket 0, which is never read
+      seen |= d;
     }
   }
 #pragma unroll
@@ -51,16 +52,17 @@ __global__ __launch_bounds__(256) void msm_digits_kernel(const uint64_t* scalars
     atomicOr((unsigned long long*)or_bits, (unsigned long long)seen);
 }
 
-// run boundaries of every key in the sorted list: first[key], last[key] (both zero = empty bucket)
+// run boundaries of every digit d >= 1 in the sorted list: first[d], last[d] (both zero = empty bucket)
 __global__ __launch_bounds__(256) void msm_bounds_kernel(SigPairs pairs, const uint64_t* or_bits, uint64_t total, uint32_t* first,
                                                          uint32_t* last) {
   const uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (p >= total) return;
+  constexpr uint64_t mask = (1ull << MSM_KEY_DIGIT_BITS) - 1;
   const uint64_t* keys = pairs.keys[sig_buffer_before(or_bits, 8)];
-  const uint64_t key = keys[p];
-  if (key == SIG_NO_WIRE) return;
-  if (p == 0 || keys[p - 1] != key) first[key] = (uint32_t)p;
-  if (p + 1 == total || keys[p + 1] != key) last[key] = (uint32_t)p + 1;
+  const uint64_t d = keys[p] & mask;
+  if (d == 0) return;
+  if (p == 0 || (keys[p - 1] & mask) != d) first[d] = (uint32_t)p;
+  if (p + 1 == total || (keys[p + 1] & mask) != d) last[d] = (uint32_t)p + 1;
 }
 
 // step 3: bucket b = sum of table[vals[p]] over its run; 2^log_t adjacent lanes share a bucket (entry j, j + 2^log_t, ...
@@ -80,10 +82,10 @@ __global__ __launch_bounds__(256, 3) void msm_bucket_sum_kernel(SigPairs pairs, 
   const uint64_t b = gid >> log_t;
   if (b >= nbuckets) return;
   const uint32_t j = (uint32_t)gid & ((1u << log_t) - 1), t = 1u << log_t;
-  const uint32_t* vals = pairs.vals[sig_buffer_before(or_bits, 8)];
+  const uint64_t* keys = pairs.keys[sig_buffer_before(or_bits, 8)];
   J28 acc = j28_inf();
   const uint32_t end = last[b];
-  for (uint32_t p = first[b] + j; p < end; p += t) acc = j28_add_affine<true>(acc, a28_load(table, vals[p]));
+  for (uint32_t p = first[b] + j; p < end; p += t) acc = j28_add_affine<true>(acc, a28_load(table, keys[p] >> MSM_KEY_DIGIT_BITS));
   j28_store(partials, gid, acc);
 }
 

@@ -54,7 +54,7 @@ __device__ __forceinline__ int sig_buffer_before(const uint64_t* or_bits, int p)
 
 struct SigPairs {
   uint64_t* keys[2];
-  uint32_t* vals[2];
+  uint32_t* vals[2];     // null when the keys carry their payload in the bits the sort does not look at
 };
 
 // pairs in position order: position = 4 * row + wire; also the OR of all used node ids
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(64) void sig_scatter_kernel(SigPairs pairs, uint64_
     const bool live = i < total;
     uint64_t key = 0;
     uint32_t val = 0, d = 0;
-    if (live) { key = keys_in[i]; val = vals_in[i]; d = sig_digit(key, 8 * pass); }
+    if (live) { key = keys_in[i]; if (vals_in) val = vals_in[i]; d = sig_digit(key, 8 * pass); }
     // lanes holding the same bin as this one: nine ballots, one per bit of the bin number
     uint64_t same = __ballot(live);
 #pragma unroll
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(64) void sig_scatter_kernel(SigPairs pairs, uint64_
     __syncthreads();                                   // every lane has read its offset
     if (live && rank == 0) off[d] += (uint32_t)__popcll(same);
     __syncthreads();
-    if (live) { keys_out[dst] = key; vals_out[dst] = val; }
+    if (live) { keys_out[dst] = key; if (vals_out) vals_out[dst] = val; }
   }
 }
 
