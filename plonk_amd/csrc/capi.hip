@@ -878,9 +878,9 @@ int launch_msm(plk_ctx* ctx, hipStream_t s, const uint64_t* scalars, size_t n, u
   if (n == 0) return PLK_OK;
   const int c = ctx->msm_c, windows = (255 + c - 1) / c;
   const uint64_t total = (uint64_t)n * windows, nbuckets = 1ull << c;
-  // lanes per bucket: 32 to 64 entries each (their partial sums are added up by a second kernel)
-  int log_t = 0;
-  while (log_t < 6 && (total >> (c + log_t + 1)) >= 32) ++log_t;
+  // lanes per bucket: about 32 entries each (measured flat between 20 and 45; their partial sums are added up by a
+  // second kernel whose cost grows with the lane count)
+  const uint32_t lanes = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, (total >> c) / 32));
   int rc;
   PairSort ps;
   if ((rc = pair_sort_alloc(ctx, s, "msm", total, &ps, false))) return rc;     // the keys carry the table index
@@ -889,7 +889,7 @@ int launch_msm(plk_ctx* ctx, hipStream_t s, const uint64_t* scalars, size_t n, u
   if ((rc = ws_get(ctx, "msm_bounds", 2 * nbuckets * 4, &pf))) return rc;
   if ((rc = ws_get(ctx, "msm_buckets", nbuckets * point_bytes, &pb))) return rc;
   void* pp_part;
-  if ((rc = ws_get(ctx, "msm_partials", (nbuckets << log_t) * point_bytes, &pp_part))) return rc;
+  if ((rc = ws_get(ctx, "msm_partials", nbuckets * lanes * point_bytes, &pp_part))) return rc;
   if ((rc = ws_get(ctx, "msm_fold", 2 * 256 * point_bytes + 2 * 144, &pa))) return rc;
   uint32_t* first = (uint32_t*)pf; uint32_t* last = first + nbuckets;
   HIP_TRY(ctx, hipMemsetAsync(pf, 0, 2 * nbuckets * 4, s));
@@ -906,13 +906,13 @@ int launch_msm(plk_ctx* ctx, hipStream_t s, const uint64_t* scalars, size_t n, u
   }
   {
     ProfScope p(ctx, s, "msm_bucket_sum_kernel", 128.0 * (double)total);   // one affine table entry per pair
-    hipLaunchKernelGGL(msm_bucket_sum_kernel, dim3((unsigned)(((nbuckets << log_t) + 255) / 256)), dim3(256), 0, s, ps.pairs,
-                       (const uint64_t*)ps.or_bits, (const uint32_t*)first, (const uint32_t*)last, nbuckets, log_t, (const uint32_t*)ctx->msm_table,
-                       (uint32_t*)(log_t ? pp_part : pb));
+    hipLaunchKernelGGL(msm_bucket_sum_kernel, dim3((unsigned)((nbuckets * lanes + 255) / 256)), dim3(256), 0, s, ps.pairs,
+                       (const uint64_t*)ps.or_bits, (const uint32_t*)first, (const uint32_t*)last, nbuckets, lanes, (const uint32_t*)ctx->msm_table,
+                       (uint32_t*)(lanes > 1 ? pp_part : pb));
   }
-  if (log_t) {
-    ProfScope p(ctx, s, "msm_bucket_combine_kernel", (double)point_bytes * (double)(nbuckets << log_t));
-    hipLaunchKernelGGL(msm_bucket_combine_kernel, dim3((unsigned)((2 * nbuckets + 255) / 256)), dim3(256), 0, s, (const uint32_t*)pp_part, nbuckets, log_t,
+  if (lanes > 1) {
+    ProfScope p(ctx, s, "msm_bucket_combine_kernel", (double)point_bytes * (double)(nbuckets * lanes));
+    hipLaunchKernelGGL(msm_bucket_combine_kernel, dim3((unsigned)((2 * nbuckets + 255) / 256)), dim3(256), 0, s, (const uint32_t*)pp_part, nbuckets, lanes,
                        (uint32_t*)pb);
   }
   // folds: 2^c points -> 2^ceil(c/2) -> ... -> 2; then sum_d d * B_d = B_1

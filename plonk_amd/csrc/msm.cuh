@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void msm_bounds_kernel(SigPairs pairs, const u
   if (p + 1 == total || (keys[p + 1] & mask) != d) last[d] = (uint32_t)p + 1;
 }
 
-// step 3: bucket b = sum of table[vals[p]] over its run; 2^log_t adjacent lanes share a bucket (entry j, j + 2^log_t, ...
+// step 3: bucket b = sum of the table entries of its run; `lanes` adjacent lanes share a bucket (entry j, j + lanes, ...
 // each), so that long runs do not serialise on one lane, and a second kernel adds their partial sums up.  (Two kernels
 // because the mixed addition alone fits three waves per SIMD; with the full addition beside it two.)
 __device__ __forceinline__ F14 f14_shfl_down(const F14& a, int delta) {
@@ -76,30 +76,31 @@ __device__ __forceinline__ F14 f14_shfl_down(const F14& a, int delta) {
 }
 
 __global__ __launch_bounds__(256, 3) void msm_bucket_sum_kernel(SigPairs pairs, const uint64_t* or_bits, const uint32_t* first,
-                                                                const uint32_t* last, uint64_t nbuckets, int log_t, const uint32_t* table,
+                                                                const uint32_t* last, uint64_t nbuckets, uint32_t lanes, const uint32_t* table,
                                                                 uint32_t* partials) {
   const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  const uint64_t b = gid >> log_t;
+  const uint64_t b = gid / lanes;
   if (b >= nbuckets) return;
-  const uint32_t j = (uint32_t)gid & ((1u << log_t) - 1), t = 1u << log_t;
+  const uint32_t j = (uint32_t)(gid - b * lanes);
   const uint64_t* keys = pairs.keys[sig_buffer_before(or_bits, 8)];
   J28 acc = j28_inf();
   const uint32_t end = last[b];
-  for (uint32_t p = first[b] + j; p < end; p += t) acc = j28_add_affine<true>(acc, a28_load(table, keys[p] >> MSM_KEY_DIGIT_BITS));
+  for (uint32_t p = first[b] + j; p < end; p += lanes) acc = j28_add_affine<true>(acc, a28_load(table, keys[p] >> MSM_KEY_DIGIT_BITS));
   j28_store(partials, gid, acc);
 }
 
-// bucket b = sum of its 2^log_t >= 2 partial sums: two lanes per bucket add up half of them each, one after the
+// bucket b = sum of its `lanes` >= 2 partial sums: two lanes per bucket add up half of them each, one after the
 // other, and combine by a shuffle (a tree over all the lanes would leave most of them adding nothing)
-__global__ __launch_bounds__(256) void msm_bucket_combine_kernel(const uint32_t* partials, uint64_t nbuckets, int log_t, uint32_t* buckets) {
+__global__ __launch_bounds__(256) void msm_bucket_combine_kernel(const uint32_t* partials, uint64_t nbuckets, uint32_t lanes, uint32_t* buckets) {
   const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;      // the grid covers whole waves: the shuffle needs every lane
   const uint64_t b = gid >> 1;
-  const uint32_t h = (uint32_t)gid & 1, per = 1u << (log_t - 1);
+  const uint32_t h = (uint32_t)gid & 1, half = (lanes + 1) / 2;
   J28 part = j28_inf();
   if (b < nbuckets) {
-    const uint64_t at = (b << log_t) + (uint64_t)h * per;
+    const uint64_t at = b * lanes + (uint64_t)h * half;
+    const uint32_t mine = h ? lanes - half : half;                    // >= 1: lanes >= 2
     part = j28_load(partials, at);
-    for (uint32_t k = 1; k < per; ++k) part = j28_add_inl(part, j28_load(partials, at + k));
+    for (uint32_t k = 1; k < mine; ++k) part = j28_add_inl(part, j28_load(partials, at + k));
   }
   J28 other;
   other.x = f14_shfl_down(part.x, 1); other.y = f14_shfl_down(part.y, 1); other.z = f14_shfl_down(part.z, 1);
