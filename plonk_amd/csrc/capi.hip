@@ -7,10 +7,15 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <map>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "constraints.cuh"
@@ -43,8 +48,68 @@ struct NttPlan {
 
 }  // namespace
 
+// Copies between ordinary (pageable) host memory and the device.  hipMemcpy stages such copies through one
+// thread; here COPY_WORKERS threads (the caller and a small pool that lives with the context) each copy chunks
+// into page-locked slots of their own and send them on streams of their own, copy and DMA overlapping.
+constexpr size_t COPY_CHUNK = size_t(4) << 20;      // bytes per slot
+constexpr size_t COPY_MIN = size_t(8) << 20;        // below this a plain hipMemcpyAsync
+constexpr int COPY_WORKERS = 10;                    // at most; fewer on a host with fewer hardware threads
+
+struct CopyLane { void* slot[2] = {nullptr, nullptr}; hipStream_t st = nullptr; hipEvent_t ev[2] = {nullptr, nullptr}; };
+
+struct CopyPool {
+  std::vector<std::thread> threads;
+  std::mutex m;
+  std::condition_variable cv_start, cv_done;
+  std::function<void(int)> job;
+  uint64_t generation = 0;
+  int pending = 0;
+  bool stop = false;
+  int workers = 1;                                    // the caller included
+  void start() {
+    workers = std::min<int>(COPY_WORKERS, std::max<int>(2, (int)std::thread::hardware_concurrency()));
+    for (int w = 1; w < workers; ++w)
+      threads.emplace_back([this, w] {
+        uint64_t seen = 0;
+        for (;;) {
+          std::function<void(int)> j;
+          {
+            std::unique_lock<std::mutex> lk(m);
+            cv_start.wait(lk, [&] { return stop || generation != seen; });
+            if (stop) return;
+            seen = generation;
+            j = job;
+          }
+          j(w);
+          std::lock_guard<std::mutex> lk(m);
+          if (--pending == 0) cv_done.notify_one();
+        }
+      });
+  }
+  // f(0) on the caller, f(1..) on the pool; returns when all are done
+  void run(const std::function<void(int)>& f) {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      job = f; pending = (int)threads.size(); ++generation;
+    }
+    cv_start.notify_all();
+    f(0);
+    std::unique_lock<std::mutex> lk(m);
+    cv_done.wait(lk, [&] { return pending == 0; });
+  }
+  void shutdown() {
+    { std::lock_guard<std::mutex> lk(m); stop = true; }
+    cv_start.notify_all();
+    for (auto& t : threads) t.join();
+    threads.clear();
+  }
+};
+
 struct plk_ctx {
   int device = 0;
+  CopyLane copy_lanes[COPY_WORKERS];
+  CopyPool copy_pool;
+  bool copy_ready = false;
   hipStream_t stream = nullptr;  // used by the host entry points
   hipStream_t aux = nullptr;     // side stream of plk_round23: the grand-product chain runs beside the transforms
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -960,6 +1025,89 @@ int fetch_status(plk_ctx* ctx, hipStream_t s) {
 // Device copies of a host entry point's arguments and results.  The buffers are slots of the
 // context's grow-only workspace ("stage0", "stage1", ... in order of use), so a repeated call of the
 // same shape allocates nothing; they are valid until the next host entry point on this context.
+bool host_is_pageable(const void* p) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return true; }   // unknown to the runtime
+  return a.type == hipMemoryTypeUnregistered;
+}
+
+int copy_lanes_init(plk_ctx* ctx) {
+  if (ctx->copy_ready) return PLK_OK;
+  for (auto& lane : ctx->copy_lanes) {
+    for (int s = 0; s < 2; ++s) {
+      if (!lane.slot[s]) HIP_TRY(ctx, hipHostMalloc(&lane.slot[s], COPY_CHUNK, hipHostMallocDefault));
+      if (!lane.ev[s]) HIP_TRY(ctx, hipEventCreateWithFlags(&lane.ev[s], hipEventDisableTiming));
+    }
+    if (!lane.st) HIP_TRY(ctx, hipStreamCreateWithFlags(&lane.st, hipStreamNonBlocking));
+  }
+  ctx->copy_pool.start();
+  ctx->copy_ready = true;
+  return PLK_OK;
+}
+
+// dst <- src, one side pageable host memory, the other device memory; returns when the bytes have arrived
+int threaded_copy(plk_ctx* ctx, void* dst, const void* src, size_t bytes, bool to_device) {
+  int rc = copy_lanes_init(ctx);
+  if (rc) return rc;
+  const size_t chunks = (bytes + COPY_CHUNK - 1) / COPY_CHUNK;
+  const size_t stride = (size_t)ctx->copy_pool.workers;
+  std::atomic<int> failed{0};
+  auto span = [&](size_t c, size_t* off) { *off = c * COPY_CHUNK; return std::min(COPY_CHUNK, bytes - *off); };
+  auto body = [&](int w) {
+    CopyLane& lane = ctx->copy_lanes[w];
+    bool ok = hipSetDevice(ctx->device) == hipSuccess;
+    int k = 0;
+    if (to_device) {
+      for (size_t c = (size_t)w; ok && c < chunks; c += stride, ++k) {
+        const int s = k & 1;
+        size_t off; const size_t len = span(c, &off);
+        if (k >= 2) ok = hipEventSynchronize(lane.ev[s]) == hipSuccess;            // the slot's previous DMA has read it
+        if (!ok) break;
+        memcpy(lane.slot[s], (const char*)src + off, len);
+        ok = hipMemcpyAsync((char*)dst + off, lane.slot[s], len, hipMemcpyHostToDevice, lane.st) == hipSuccess &&
+             hipEventRecord(lane.ev[s], lane.st) == hipSuccess;
+      }
+    } else {
+      auto fetch = [&](size_t c, int s) {
+        size_t off; const size_t len = span(c, &off);
+        return hipMemcpyAsync(lane.slot[s], (const char*)src + off, len, hipMemcpyDeviceToHost, lane.st) == hipSuccess &&
+               hipEventRecord(lane.ev[s], lane.st) == hipSuccess;
+      };
+      if ((size_t)w < chunks) ok = ok && fetch((size_t)w, 0);
+      for (size_t c = (size_t)w; ok && c < chunks; c += stride, ++k) {        // DMA of the next chunk runs beside this memcpy
+        const int s = k & 1;
+        if (c + stride < chunks) ok = fetch(c + stride, s ^ 1);
+        ok = ok && hipEventSynchronize(lane.ev[s]) == hipSuccess;
+        if (!ok) break;
+        size_t off; const size_t len = span(c, &off);
+        memcpy((char*)dst + off, lane.slot[s], len);
+      }
+    }
+    if (hipStreamSynchronize(lane.st) != hipSuccess) ok = false;
+    if (!ok) failed = 1;
+  };
+  ctx->copy_pool.run(body);
+  if (failed) { (void)hipGetLastError(); return fail(ctx, PLK_ERR_HIP, "copy between host and device memory failed"); }
+  return PLK_OK;
+}
+
+// host -> device on the context's stream (the staging slot is fresh, nothing enqueued touches it)
+int upload_bytes(plk_ctx* ctx, void* dst, const void* host, size_t bytes) {
+  if (bytes >= COPY_MIN && host_is_pageable(host)) return threaded_copy(ctx, dst, host, bytes, true);
+  HIP_TRY(ctx, hipMemcpyAsync(dst, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return PLK_OK;
+}
+
+// device -> host behind everything enqueued on the context's stream; the caller synchronises the stream afterwards
+int download(plk_ctx* ctx, void* host, const void* src, size_t bytes) {
+  if (bytes >= COPY_MIN && host_is_pageable(host)) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return threaded_copy(ctx, host, src, bytes, false);
+  }
+  HIP_TRY(ctx, hipMemcpyAsync(host, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  return PLK_OK;
+}
+
 struct Staged {
   plk_ctx* ctx;
   int used = 0;
@@ -970,8 +1118,7 @@ struct Staged {
   int upload(const void* host, size_t bytes, void** out) {
     int rc = alloc(bytes, out);
     if (rc) return rc;
-    if (bytes) HIP_TRY(ctx, hipMemcpyAsync(*out, host, bytes, hipMemcpyHostToDevice, ctx->stream));
-    return PLK_OK;
+    return bytes ? upload_bytes(ctx, *out, host, bytes) : PLK_OK;
   }
 };
 
@@ -1037,6 +1184,11 @@ void plk_ctx_destroy(plk_ctx* ctx) {
   }
   for (auto& kv : ctx->ws) if (kv.second.p) (void)hipFree(kv.second.p);
   msm_free_table(ctx);
+  ctx->copy_pool.shutdown();
+  for (auto& lane : ctx->copy_lanes) {
+    for (int s = 0; s < 2; ++s) { if (lane.slot[s]) (void)hipHostFree(lane.slot[s]); if (lane.ev[s]) (void)hipEventDestroy(lane.ev[s]); }
+    if (lane.st) (void)hipStreamDestroy(lane.st);
+  }
   for (auto& kv : ctx->powers) { if (kv.second.lo.p) (void)hipFree(kv.second.lo.p); if (kv.second.hi.p) (void)hipFree(kv.second.hi.p); }
   for (auto& r : ctx->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   for (auto& e : ctx->event_pool) (void)hipEventDestroy(e);
@@ -1373,7 +1525,7 @@ int plk_intt(plk_ctx* ctx, const uint64_t* evals, size_t evals_len, size_t domai
   const uint64_t* in[1] = {(const uint64_t*)d};
   uint64_t* out[1] = {(uint64_t*)d};
   if ((rc = launch_ntt(ctx, ctx->stream, in, nullptr, 1, domain_size, domain_size, true, out))) return rc;
-  HIP_TRY(ctx, hipMemcpyAsync(coeffs_out, d, domain_size * ELEM, hipMemcpyDeviceToHost, ctx->stream));
+  { int rc_ = download(ctx, coeffs_out, d, domain_size * ELEM); if (rc_) return rc_; }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return PLK_OK;
 }
@@ -1400,7 +1552,7 @@ int plk_ntt(plk_ctx* ctx, const uint64_t* coeffs, size_t n_coeffs, size_t domain
   const uint64_t* in[1] = {(const uint64_t*)d_in};
   uint64_t* out[1] = {(uint64_t*)d_out};
   if ((rc = launch_ntt(ctx, ctx->stream, in, nullptr, 1, n_coeffs, domain_size, false, out))) return rc;
-  HIP_TRY(ctx, hipMemcpyAsync(evals_out, d_out, domain_size * ELEM, hipMemcpyDeviceToHost, ctx->stream));
+  { int rc_ = download(ctx, evals_out, d_out, domain_size * ELEM); if (rc_) return rc_; }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return PLK_OK;
 }
@@ -1426,7 +1578,7 @@ int plk_gate_polys(plk_ctx* ctx, const uint64_t* const wires[4], const uint64_t*
     in[m] = (const uint64_t*)d; out[m] = (uint64_t*)d; host_out[m] = sel_out[k]; ++m;
   }
   if ((rc = launch_ntt(ctx, ctx->stream, in, nullptr, m, n, domain_size, true, out))) return rc;
-  for (size_t b = 0; b < m; ++b) HIP_TRY(ctx, hipMemcpyAsync(host_out[b], out[b], n * ELEM, hipMemcpyDeviceToHost, ctx->stream));
+  for (size_t b = 0; b < m; ++b) { int rc_ = download(ctx, host_out[b], out[b], n * ELEM); if (rc_) return rc_; }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return PLK_OK;
 }
@@ -1455,7 +1607,7 @@ int plk_gate_constraints(plk_ctx* ctx, const uint64_t* const wire_coeffs[4], con
   for (size_t b = 0; b < m; ++b) { if (col[b] < 4) w[col[b]] = ev[b]; else s[col[b] - 4] = ev[b]; }
   void* d_out; if ((rc = st.alloc(N * ELEM, &d_out))) return rc;
   if ((rc = launch_gate_eval(ctx, ctx->stream, w, s, N, (uint64_t*)d_out))) return rc;
-  HIP_TRY(ctx, hipMemcpyAsync(out_host, d_out, N * ELEM, hipMemcpyDeviceToHost, ctx->stream));
+  { int rc_ = download(ctx, out_host, d_out, N * ELEM); if (rc_) return rc_; }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return PLK_OK;
 }
@@ -1475,7 +1627,7 @@ int plk_grand_product(plk_ctx* ctx, const uint64_t* const wires[4], const uint64
   void* dz; if ((rc = st.alloc((n + 1) * ELEM, &dz))) return rc;
   if ((rc = launch_grand_product(ctx, ctx->stream, w, sg, n, beta, gamma, (uint64_t*)dz))) return rc;
   if ((rc = fetch_status(ctx, ctx->stream))) return rc;
-  HIP_TRY(ctx, hipMemcpyAsync(z_out, dz, (n + 1) * ELEM, hipMemcpyDeviceToHost, ctx->stream));
+  { int rc_ = download(ctx, z_out, dz, (n + 1) * ELEM); if (rc_) return rc_; }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return PLK_OK;
 }
@@ -1515,7 +1667,7 @@ int plk_coset_ntt(plk_ctx* ctx, const uint64_t* in, size_t n_in, size_t domain_s
   const uint64_t* ip[1] = {(const uint64_t*)d_in};
   uint64_t* op[1] = {(uint64_t*)d_out};
   if ((rc = launch_coset_ntt(ctx, ctx->stream, ip, 1, n_in, domain_size, shift, inverse != 0, op))) return rc;
-  HIP_TRY(ctx, hipMemcpyAsync(out, d_out, domain_size * ELEM, hipMemcpyDeviceToHost, ctx->stream));
+  { int rc_ = download(ctx, out, d_out, domain_size * ELEM); if (rc_) return rc_; }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return PLK_OK;
 }
@@ -1536,7 +1688,7 @@ int plk_quotient(plk_ctx* ctx, const uint64_t* const* numerators, size_t count, 
   void* d_out;
   if ((rc = st.alloc(N * ELEM, &d_out))) return rc;
   if ((rc = launch_quotient(ctx, ctx->stream, d, count, alpha, n, N, shift, (uint64_t*)d_out))) return rc;
-  HIP_TRY(ctx, hipMemcpyAsync(coeffs_out, d_out, N * ELEM, hipMemcpyDeviceToHost, ctx->stream));
+  { int rc_ = download(ctx, coeffs_out, d_out, N * ELEM); if (rc_) return rc_; }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return PLK_OK;
 }
@@ -1564,8 +1716,8 @@ int plk_gate_table_fill(plk_ctx* ctx, const uint8_t* row_ops, const uint64_t* co
     if (sel_out && sel_out[k]) { void* e; if ((rc = st.alloc(n * ELEM, &e))) return rc; sl[k] = (uint64_t*)e; }
   }
   if ((rc = launch_gate_table_fill(ctx, ctx->stream, (const uint8_t*)ops, nd, n, (const uint64_t*)vals, n_values, default_val, w, sl))) return rc;
-  for (int k = 0; k < 4; ++k) HIP_TRY(ctx, hipMemcpyAsync(wires_out[k], w[k], n * ELEM, hipMemcpyDeviceToHost, ctx->stream));
-  for (int k = 0; k < 9; ++k) if (sl[k]) HIP_TRY(ctx, hipMemcpyAsync(sel_out[k], sl[k], n * ELEM, hipMemcpyDeviceToHost, ctx->stream));
+  for (int k = 0; k < 4; ++k) { int rc_ = download(ctx, wires_out[k], w[k], n * ELEM); if (rc_) return rc_; }
+  for (int k = 0; k < 9; ++k) if (sl[k]) { int rc_ = download(ctx, sel_out[k], sl[k], n * ELEM); if (rc_) return rc_; }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return PLK_OK;
 }
@@ -1583,7 +1735,7 @@ int plk_sigma_table(plk_ctx* ctx, const uint64_t* const node_ids[4], size_t n, u
     nd[k] = (const uint64_t*)d; sg[k] = (uint64_t*)e;
   }
   if ((rc = launch_sigma_table(ctx, ctx->stream, nd, n, sg))) return rc;
-  for (int k = 0; k < 4; ++k) HIP_TRY(ctx, hipMemcpyAsync(sigma_out[k], sg[k], n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  for (int k = 0; k < 4; ++k) { int rc_ = download(ctx, sigma_out[k], sg[k], n * 8); if (rc_) return rc_; }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return PLK_OK;
 }
@@ -1614,8 +1766,8 @@ int plk_perm_polys(plk_ctx* ctx, const uint64_t* const wires[4], const uint64_t*
   }
   in[4] = (const uint64_t*)dz; kinds[4] = NTT_IN_FIELD; out[4] = (uint64_t*)dz;
   if ((rc = launch_ntt(ctx, ctx->stream, in, kinds, 5, n, domain_size, true, out))) return rc;
-  for (int k = 0; k < 4; ++k) HIP_TRY(ctx, hipMemcpyAsync(sigma_coeffs_out[k], out[k], n * ELEM, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(z_coeffs_out, dz, n * ELEM, hipMemcpyDeviceToHost, ctx->stream));
+  for (int k = 0; k < 4; ++k) { int rc_ = download(ctx, sigma_coeffs_out[k], out[k], n * ELEM); if (rc_) return rc_; }
+  { int rc_ = download(ctx, z_coeffs_out, dz, n * ELEM); if (rc_) return rc_; }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return PLK_OK;
 }
@@ -1642,7 +1794,7 @@ int plk_perm_constraints(plk_ctx* ctx, const uint64_t* z_coeffs, const uint64_t*
   const uint64_t* w[4] = {ev[5], ev[6], ev[7], ev[8]};
   void* d_out; if ((rc = st.alloc(N * ELEM, &d_out))) return rc;
   if ((rc = launch_perm_eval(ctx, ctx->stream, ev[0], sg, w, N, beta, gamma, z_shift, (uint64_t*)d_out))) return rc;
-  HIP_TRY(ctx, hipMemcpyAsync(out_host, d_out, N * ELEM, hipMemcpyDeviceToHost, ctx->stream));
+  { int rc_ = download(ctx, out_host, d_out, N * ELEM); if (rc_) return rc_; }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return PLK_OK;
 }
@@ -1673,9 +1825,9 @@ int plk_round23(plk_ctx* ctx, const uint64_t* const wires[4], const uint64_t* co
   if ((rc = st.alloc(N * ELEM, &dp))) return rc;
   if ((rc = launch_round23(ctx, ctx->stream, w, s, sg, n, N, beta, gamma, z_shift, (uint64_t*)dz, (uint64_t*)dg, (uint64_t*)dp))) return rc;
   if ((rc = fetch_status(ctx, ctx->stream))) return rc;
-  if (z_out) HIP_TRY(ctx, hipMemcpyAsync(z_out, dz, (n + 1) * ELEM, hipMemcpyDeviceToHost, ctx->stream));
-  if (gate_out) HIP_TRY(ctx, hipMemcpyAsync(gate_out, dg, N * ELEM, hipMemcpyDeviceToHost, ctx->stream));
-  if (perm_out) HIP_TRY(ctx, hipMemcpyAsync(perm_out, dp, N * ELEM, hipMemcpyDeviceToHost, ctx->stream));
+  if (z_out) { int rc_ = download(ctx, z_out, dz, (n + 1) * ELEM); if (rc_) return rc_; }
+  if (gate_out) { int rc_ = download(ctx, gate_out, dg, N * ELEM); if (rc_) return rc_; }
+  if (perm_out) { int rc_ = download(ctx, perm_out, dp, N * ELEM); if (rc_) return rc_; }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return PLK_OK;
 }
