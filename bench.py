@@ -220,12 +220,16 @@ def other_workloads(args, prover, dist, rank, world):
         dt = timed(lambda: prover.msm(s_dev), args.steps, args.warmup, dist, prover.device)
         prof = prover.profile_end()
         ms = dt * 1e3 / args.steps
+        # four commitments at once (the wire polynomials of one round), overlapped on two streams
+        four = [s_dev] + [to_device(synth.random_elements(600 + 10 * rank + k, n), prover.device) for k in range(3)]
+        assert (prover.msm_batch(four)[0] == out).all()
+        ms_each_of_four = timed(lambda: prover.msm_batch(four), max(2, args.steps // 2), 1, dist, prover.device) * 1e3 / max(2, args.steps // 2) / 4
         alg = (32.0 + 96.0) * n                     # one scalar and one affine base per term
         line = dict(base, metric=f"G1 multi-scalar multiplication of 2^{args.log_n} terms (one KZG commitment)", value=round(ms, 4),
                     unit="ms", ms_per_step=round(ms, 4), higher_is_better=False, scaling="weak", dtype="u32",
                     config={"workload": f"sum of 2^{args.log_n} scalar * point products in BLS12-381 G1 per GPU, bases resident, "
                                         f"result (affine) on the host"},
-                    terms_per_s=round(n / (ms * 1e-3), 1),
+                    terms_per_s=round(n / (ms * 1e-3), 1), ms_each_in_a_batch_of_4=round(ms_each_of_four, 4),
                     roofline={"bound": "hbm", "achieved": round(alg / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
                               "note": "whole step; 128 algorithmic bytes per term; the work is ~180 base-field products per "

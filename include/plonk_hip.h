@@ -201,6 +201,10 @@ int plk_quotient(plk_ctx* ctx, const uint64_t* const* numerators, size_t count, 
  * digits spread over the 2^c buckets: a few lanes add up each bucket, so n equal scalars serialise. */
 int plk_msm_set_bases(plk_ctx* ctx, const uint64_t* bases_host, size_t n);
 int plk_msm_g1(plk_ctx* ctx, const uint64_t* scalars_host, size_t n, uint64_t out_xy[12]);
+/* `count` sums over the same bases, scalars[k] holding n elements each: the commitments of one prover round (the
+ * four wire polynomials, the parts of the quotient); results at out_xy[12 k ...].  The sums alternate between two
+ * streams, so that one sum's latency-bound bucket reduction runs beside the next one's additions. */
+int plk_msm_g1_batch(plk_ctx* ctx, const uint64_t* const scalars_host[], size_t count, size_t n, uint64_t* out_xy);
 
 /* ---- device entry points (same arithmetic, device pointers, asynchronous) ---------------- */
 
@@ -241,6 +245,7 @@ int plk_dev_twiddle_block(plk_ctx* ctx, void* stream, size_t N, int inverse, int
 
 int plk_dev_msm_set_bases(plk_ctx* ctx, const uint64_t* bases_dev, size_t n);
 int plk_dev_msm_g1(plk_ctx* ctx, void* stream, const uint64_t* scalars_dev, size_t n, uint64_t out_xy[12]);
+int plk_dev_msm_g1_batch(plk_ctx* ctx, void* stream, const uint64_t* const scalars_dev[], size_t count, size_t n, uint64_t* out_xy);
 int plk_dev_g1_multiples(plk_ctx* ctx, void* stream, const uint64_t base_xy[12], uint64_t first, size_t count, uint64_t* out_dev);
 
 /* plk_coset_ntt for `batch` device columns, plk_quotient on device vectors (alpha, shift stay host pointers) */

@@ -390,6 +390,19 @@ inline G1Affine multi_scalar_mul(const std::vector<Fr>& scalars, Context& ctx = 
   return out;
 }
 
+// the commitments of several polynomials of one length at once (one prover round), overlapped on the GPU
+inline std::vector<G1Affine> multi_scalar_mul_batch(const std::vector<std::vector<Fr>>& scalar_columns, Context& ctx = Context::global()) {
+  std::vector<G1Affine> out(scalar_columns.size());
+  if (scalar_columns.empty()) return out;
+  std::vector<const uint64_t*> p;
+  for (const auto& v : scalar_columns) {
+    if (v.size() != scalar_columns[0].size()) throw LengthMismatch(PLK_ERR_LENGTH, plk_strerror(PLK_ERR_LENGTH));
+    p.push_back(detail::ptr(v));
+  }
+  ctx.check(plk_msm_g1_batch(ctx.get(), p.data(), p.size(), scalar_columns[0].size(), out[0].data()));
+  return out;
+}
+
 // KZG10::commit without hiding: the commitment of a polynomial under the bases set above
 inline G1Affine commit(const DensePolynomial& polynomial, Context& ctx = Context::global()) { return multi_scalar_mul(polynomial.coeffs, ctx); }
 

@@ -59,8 +59,10 @@ SIGNATURES = {
     "plk_dev_gate_table_fill": (C.c_int, [C.c_void_p, C.c_void_p, u8p, u64pp, C.c_size_t, u64p, C.c_size_t, u64p, u64pp, u64pp]),
     "plk_msm_set_bases": (C.c_int, [C.c_void_p, u64p, C.c_size_t]),
     "plk_msm_g1": (C.c_int, [C.c_void_p, u64p, C.c_size_t, u64p]),
+    "plk_msm_g1_batch": (C.c_int, [C.c_void_p, u64pp, C.c_size_t, C.c_size_t, u64p]),
     "plk_dev_msm_set_bases": (C.c_int, [C.c_void_p, u64p, C.c_size_t]),
     "plk_dev_msm_g1": (C.c_int, [C.c_void_p, C.c_void_p, u64p, C.c_size_t, u64p]),
+    "plk_dev_msm_g1_batch": (C.c_int, [C.c_void_p, C.c_void_p, u64pp, C.c_size_t, C.c_size_t, u64p]),
     "plk_dev_g1_multiples": (C.c_int, [C.c_void_p, C.c_void_p, u64p, C.c_uint64, C.c_size_t, u64p]),
     "plk_coset_ntt": (C.c_int, [C.c_void_p, u64p, C.c_size_t, C.c_size_t, u64p, C.c_int, u64p]),
     "plk_quotient": (C.c_int, [C.c_void_p, u64pp, C.c_size_t, u64p, C.c_size_t, C.c_size_t, u64p, u64p]),

@@ -399,6 +399,18 @@ def msm_g1(scalars: np.ndarray, ctx: Optional[Context] = None) -> np.ndarray:
     return out
 
 
+def msm_g1_batch(scalar_columns: Sequence[np.ndarray], ctx: Optional[Context] = None) -> np.ndarray:
+    """One sum per column over the same bases (the commitments of one prover round): `(count, 12) uint64`."""
+    c = _ctx(ctx)
+    cols = [_col(s, "scalars") for s in scalar_columns]
+    if len({s.shape[0] for s in cols}) > 1:
+        raise ValueError("scalar columns differ in length")
+    out = np.zeros((len(cols), 12), dtype=np.uint64)
+    if cols:
+        c.check(c.lib.plk_msm_g1_batch(c.handle, _table(cols), len(cols), cols[0].shape[0], _p(out)))
+    return out
+
+
 def row_ops(kinds: Sequence[str], inputs: Sequence[int]) -> np.ndarray:
     """Row descriptors of the flattened trace: `ASTKind` index | number of inputs << 4, one byte per row."""
     k = np.array([AST_KINDS.index(x) for x in kinds], dtype=np.uint8)

@@ -120,6 +120,8 @@ struct plk_ctx {
   uint32_t* msm_table = nullptr;                 // affine G1 points 2^(c w) * base_i at [w * msm_nbases + i] (msm.cuh), 128 bytes each
   size_t msm_nbases = 0;
   int msm_c = 0;                                 // window width the table was built for
+  G1Jac* msm_sums = nullptr;                     // page-locked landing place of the sums (Jacobian, ABI form)
+  size_t msm_sums_cap = 0;
   size_t gp_rows = 0;                            // rows of the grand-product range held in the workspace
   GpStatus* status_dev = nullptr;
   GpStatus* status_host = nullptr;  // pinned
@@ -934,13 +936,11 @@ int msm_build_table(plk_ctx* ctx, hipStream_t s, const uint64_t* bases, size_t n
   return PLK_OK;
 }
 
-// sum_i scalars[i] * bases[i], i < n, scalars on the device (Montgomery Fr), bases = the context's table;
-// the affine result (x, y; (0, 0) = infinity) goes to host memory.  Waits for the stream.
-int launch_msm(plk_ctx* ctx, hipStream_t s, const uint64_t* scalars, size_t n, uint64_t out_xy[12]) {
-  if (!scalars || !out_xy) return fail(ctx, PLK_ERR_ARG, "null pointer");
-  if (n > ctx->msm_nbases) return fail(ctx, PLK_ERR_LENGTH, "more scalars than bases set with plk_msm_set_bases");
-  for (int i = 0; i < 12; ++i) out_xy[i] = 0;
-  if (n == 0) return PLK_OK;
+// Enqueues sum_i scalars[i] * bases[i], 0 < n <= number of bases, scalars on the device (Montgomery Fr), bases = the
+// context's table, on stream s; the sum arrives in *host_sum (page-locked) as a Jacobian point in the ABI form.
+// `slot` names the workspace: sums in flight at the same time on different streams need different slots.
+int msm_enqueue(plk_ctx* ctx, hipStream_t s, const uint64_t* scalars, size_t n, int slot, G1Jac* host_sum) {
+  const std::string ws = "msm" + std::to_string(slot);
   const int c = ctx->msm_c, windows = (255 + c - 1) / c;
   const uint64_t total = (uint64_t)n * windows, nbuckets = 1ull << c;
   // lanes per bucket: about 32 entries each (measured flat between 20 and 45; their partial sums are added up by a
@@ -948,14 +948,14 @@ int launch_msm(plk_ctx* ctx, hipStream_t s, const uint64_t* scalars, size_t n, u
   const uint32_t lanes = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, (total >> c) / 32));
   int rc;
   PairSort ps;
-  if ((rc = pair_sort_alloc(ctx, s, "msm", total, &ps, false))) return rc;     // the keys carry the table index
+  if ((rc = pair_sort_alloc(ctx, s, ws, total, &ps, false))) return rc;     // the keys carry the table index
   void *pf, *pb, *pa;
   constexpr size_t point_bytes = J28_WORDS * 4;
-  if ((rc = ws_get(ctx, "msm_bounds", 2 * nbuckets * 4, &pf))) return rc;
-  if ((rc = ws_get(ctx, "msm_buckets", nbuckets * point_bytes, &pb))) return rc;
+  if ((rc = ws_get(ctx, ws + "_bounds", 2 * nbuckets * 4, &pf))) return rc;
+  if ((rc = ws_get(ctx, ws + "_buckets", nbuckets * point_bytes, &pb))) return rc;
   void* pp_part;
-  if ((rc = ws_get(ctx, "msm_partials", nbuckets * lanes * point_bytes, &pp_part))) return rc;
-  if ((rc = ws_get(ctx, "msm_fold", 2 * 256 * point_bytes + 2 * 144, &pa))) return rc;
+  if ((rc = ws_get(ctx, ws + "_partials", nbuckets * lanes * point_bytes, &pp_part))) return rc;
+  if ((rc = ws_get(ctx, ws + "_fold", 2 * 256 * point_bytes + 2 * 144, &pa))) return rc;
   uint32_t* first = (uint32_t*)pf; uint32_t* last = first + nbuckets;
   HIP_TRY(ctx, hipMemsetAsync(pf, 0, 2 * nbuckets * 4, s));
   {
@@ -992,13 +992,48 @@ int launch_msm(plk_ctx* ctx, hipStream_t s, const uint64_t* scalars, size_t n, u
     in = pp[flip]; flip ^= 1; cc = next;
   }
   HIP_TRY(ctx, hipGetLastError());
-  G1Jac sum;
-  HIP_TRY(ctx, hipMemcpyAsync(&sum, last_two + 18, 144, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipMemcpyAsync(host_sum, last_two + 18, 144, hipMemcpyDeviceToHost, s));
+  return PLK_OK;
+}
+
+// `count` sums over the same bases, scalars[k] on the device with n elements each; the affine results (x, y; (0, 0) =
+// infinity) go to out_xy[12 k ...] in host memory.  Waits for the stream.  With more than one sum they alternate
+// between s and the context's side stream, so that one sum's latency-bound bucket reduction runs beside the next
+// one's additions.
+int launch_msm(plk_ctx* ctx, hipStream_t s, const uint64_t* const* scalars, size_t count, size_t n, uint64_t* out_xy) {
+  if (!scalars || !out_xy) return fail(ctx, PLK_ERR_ARG, "null pointer");
+  for (size_t k = 0; k < count; ++k) if (!scalars[k] && n) return fail(ctx, PLK_ERR_ARG, "null pointer");
+  if (n > ctx->msm_nbases) return fail(ctx, PLK_ERR_LENGTH, "more scalars than bases set with plk_msm_set_bases");
+  for (size_t i = 0; i < 12 * count; ++i) out_xy[i] = 0;
+  if (n == 0 || count == 0) return PLK_OK;
+  if (ctx->msm_sums_cap < count) {
+    if (ctx->msm_sums) HIP_TRY(ctx, hipHostFree(ctx->msm_sums));
+    ctx->msm_sums = nullptr; ctx->msm_sums_cap = 0;
+    HIP_TRY(ctx, hipHostMalloc((void**)&ctx->msm_sums, std::max<size_t>(count, 8) * sizeof(G1Jac), hipHostMallocDefault));
+    ctx->msm_sums_cap = std::max<size_t>(count, 8);
+  }
+  int rc = PLK_OK;
+  const bool two = count > 1 && s != ctx->aux;
+  if (two) {
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, s));              // the scalars are ready where s stands now
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
+  }
+  for (size_t k = 0; k < count && rc == PLK_OK; ++k) {
+    const int slot = two ? (int)(k & 1) : 0;
+    rc = msm_enqueue(ctx, slot ? ctx->aux : s, scalars[k], n, slot, ctx->msm_sums + k);
+  }
+  if (two) {                                                    // also on an error: s must not run ahead of the side stream
+    (void)hipEventRecord(ctx->ev_join, ctx->aux);
+    (void)hipStreamWaitEvent(s, ctx->ev_join, 0);
+  }
+  if (rc) return rc;
   HIP_TRY(ctx, hipStreamSynchronize(s));
-  const G1Affine r = g1_to_affine(sum);      // one base-field inversion, on the host
-  for (int i = 0; i < 6; ++i) {
-    out_xy[i] = (uint64_t)r.x.l[2 * i] | ((uint64_t)r.x.l[2 * i + 1] << 32);
-    out_xy[6 + i] = (uint64_t)r.y.l[2 * i] | ((uint64_t)r.y.l[2 * i + 1] << 32);
+  for (size_t k = 0; k < count; ++k) {
+    const G1Affine r = g1_to_affine(ctx->msm_sums[k]);      // one base-field inversion each, on the host
+    for (int i = 0; i < 6; ++i) {
+      out_xy[12 * k + i] = (uint64_t)r.x.l[2 * i] | ((uint64_t)r.x.l[2 * i + 1] << 32);
+      out_xy[12 * k + 6 + i] = (uint64_t)r.y.l[2 * i] | ((uint64_t)r.y.l[2 * i + 1] << 32);
+    }
   }
   return PLK_OK;
 }
@@ -1184,6 +1219,7 @@ void plk_ctx_destroy(plk_ctx* ctx) {
   }
   for (auto& kv : ctx->ws) if (kv.second.p) (void)hipFree(kv.second.p);
   msm_free_table(ctx);
+  if (ctx->msm_sums) (void)hipHostFree(ctx->msm_sums);
   ctx->copy_pool.shutdown();
   for (auto& lane : ctx->copy_lanes) {
     for (int s = 0; s < 2; ++s) { if (lane.slot[s]) (void)hipHostFree(lane.slot[s]); if (lane.ev[s]) (void)hipEventDestroy(lane.ev[s]); }
@@ -1332,7 +1368,15 @@ int plk_dev_msm_set_bases(plk_ctx* ctx, const uint64_t* bases_dev, size_t n) {
 int plk_dev_msm_g1(plk_ctx* ctx, void* stream, const uint64_t* scalars_dev, size_t n, uint64_t out_xy[12]) {
   int rc = use_device(ctx);
   if (rc) return rc;
-  return launch_msm(ctx, (hipStream_t)stream, scalars_dev, n, out_xy);
+  if (!scalars_dev && n) return fail(ctx, PLK_ERR_ARG, "null pointer");
+  const uint64_t* one[1] = {scalars_dev};
+  return launch_msm(ctx, (hipStream_t)stream, one, 1, n, out_xy);
+}
+
+int plk_dev_msm_g1_batch(plk_ctx* ctx, void* stream, const uint64_t* const scalars_dev[], size_t count, size_t n, uint64_t* out_xy) {
+  int rc = use_device(ctx);
+  if (rc) return rc;
+  return launch_msm(ctx, (hipStream_t)stream, scalars_dev, count, n, out_xy);
 }
 
 int plk_dev_g1_multiples(plk_ctx* ctx, void* stream, const uint64_t base_xy[12], uint64_t first, size_t count, uint64_t* out_dev) {
@@ -1653,7 +1697,23 @@ int plk_msm_g1(plk_ctx* ctx, const uint64_t* scalars_host, size_t n, uint64_t ou
   Staged st(ctx);
   void* d;
   if ((rc = st.upload(scalars_host, n * ELEM, &d))) return rc;
-  return launch_msm(ctx, ctx->stream, (const uint64_t*)d, n, out_xy);
+  const uint64_t* one[1] = {(const uint64_t*)d};
+  return launch_msm(ctx, ctx->stream, one, 1, n, out_xy);
+}
+
+int plk_msm_g1_batch(plk_ctx* ctx, const uint64_t* const scalars_host[], size_t count, size_t n, uint64_t* out_xy) {
+  int rc = use_device(ctx);
+  if (rc) return rc;
+  if (!scalars_host && count) return fail(ctx, PLK_ERR_ARG, "null pointer");
+  Staged st(ctx);
+  std::vector<const uint64_t*> d(count);
+  for (size_t k = 0; k < count; ++k) {
+    if (!scalars_host[k] && n) return fail(ctx, PLK_ERR_ARG, "null pointer");
+    void* p;
+    if ((rc = st.upload(scalars_host[k], n * ELEM, &p))) return rc;
+    d[k] = (const uint64_t*)p;
+  }
+  return launch_msm(ctx, ctx->stream, d.data(), count, n, out_xy);
 }
 
 int plk_coset_ntt(plk_ctx* ctx, const uint64_t* in, size_t n_in, size_t domain_size, const uint64_t shift[4], int inverse, uint64_t* out) {

@@ -109,6 +109,14 @@ class DeviceProver:
         self.ctx.check(self.lib.plk_dev_msm_g1(self.ctx.handle, self._stream(), _ptr(scalars), scalars.shape[0], out.ctypes.data_as(_lib.u64p)))
         return out
 
+    def msm_batch(self, scalar_columns: Sequence[torch.Tensor]) -> np.ndarray:
+        """One sum per device column over the same bases; returns `(count, 12) uint64` (host)."""
+        out = np.zeros((len(scalar_columns), 12), dtype=np.uint64)
+        if len(scalar_columns):
+            self.ctx.check(self.lib.plk_dev_msm_g1_batch(self.ctx.handle, self._stream(), _table(scalar_columns), len(scalar_columns),
+                                                         scalar_columns[0].shape[0], out.ctypes.data_as(_lib.u64p)))
+        return out
+
     def coset_ntt(self, cols: Sequence[torch.Tensor], N: int, shift, inverse: bool = False, n_in: Optional[int] = None) -> List[torch.Tensor]:
         """coset_fft (n_in coefficients -> N evaluations on shift * <omega_N>) or coset_ifft of each column."""
         n_in = cols[0].shape[0] if n_in is None else n_in

@@ -272,6 +272,12 @@ static void test_commitment() {
   const std::vector<Fr> few(f.coeffs.begin(), f.coeffs.begin() + 5);   // fewer scalars than bases
   CHECK(orc_g1_msm(few[0].data(), bases[0].data(), few.size(), want.data()) == 0);
   CHECK(multi_scalar_mul(few) == want);
+  const std::vector<std::vector<Fr>> cols = {f.coeffs, random_column(n), random_column(n)};
+  const std::vector<G1Affine> many = multi_scalar_mul_batch(cols);
+  for (size_t k = 0; k < cols.size(); ++k) {
+    CHECK(orc_g1_msm(cols[k][0].data(), bases[0].data(), n, want.data()) == 0);
+    CHECK(many[k] == want);
+  }
   bool threw = false;
   try { multi_scalar_mul(random_column(n + 1)); } catch (const Error&) { threw = true; }
   CHECK(threw);

@@ -95,3 +95,18 @@ def test_msm_vs_c_oracle(prover):
     s = synth.random_elements(4242, n)
     got = prover.msm(to_device(s, prover.device))
     assert np.array_equal(got, co.g1_msm(s, to_host(bases)))
+
+
+def test_msm_batch(prover, ctx):
+    """Several sums over one table at once (two streams inside): each equals the single call, from device and host scalars."""
+    n = 1 << 13
+    bases = prover.g1_multiples(G, 3, n)
+    prover.msm_set_bases(bases)
+    cols = [synth.random_elements(900 + k, n) for k in range(5)]
+    dev = [to_device(c, prover.device) for c in cols]
+    single = np.stack([prover.msm(d) for d in dev])
+    assert np.array_equal(prover.msm_batch(dev), single)
+    assert np.array_equal(prover.msm_batch(dev[:1]), single[:1])
+    assert prover.msm_batch([]).shape == (0, 12)
+    pa.msm_set_bases(to_host(bases), ctx=ctx)
+    assert np.array_equal(pa.msm_g1_batch(cols, ctx=ctx), single)
