@@ -165,26 +165,40 @@ __global__ __launch_bounds__(64) void sig_scatter_kernel(SigPairs pairs, uint64_
   }
   __syncthreads();
   const uint64_t lane_lt = (1ull << threadIdx.x) - 1;
-  for (int it = 0; it < SIG_CHUNK / 64; ++it) {
-    const uint64_t i = base + it * 64 + threadIdx.x;
-    const bool live = i < total;
-    uint64_t key = 0;
-    uint32_t val = 0, d = 0;
-    if (live) { key = keys_in[i]; if (vals_in) val = vals_in[i]; d = sig_digit(key, 8 * pass); }
-    // lanes holding the same bin as this one: nine ballots, one per bit of the bin number
-    uint64_t same = __ballot(live);
+  // the chunk is read in groups of SIG_PREFETCH rounds before any of them is ranked: ranking is a chain of ballots,
+  // LDS updates and barriers per round, and a load issued inside it would be waited for every time
+  constexpr int SIG_PREFETCH = 8;
+  for (int it0 = 0; it0 < SIG_CHUNK / 64; it0 += SIG_PREFETCH) {
+    uint64_t kk[SIG_PREFETCH];
+    uint32_t vv[SIG_PREFETCH];
 #pragma unroll
-    for (int b = 0; b < 9; ++b) {
-      const uint64_t m = __ballot(live && ((d >> b) & 1u));
-      same &= ((d >> b) & 1u) ? m : ~m;
+    for (int u = 0; u < SIG_PREFETCH; ++u) {
+      const uint64_t i = base + (uint64_t)(it0 + u) * 64 + threadIdx.x;
+      kk[u] = i < total ? keys_in[i] : 0;
+      vv[u] = (i < total && vals_in) ? vals_in[i] : 0;
     }
-    const uint32_t rank = (uint32_t)__popcll(same & lane_lt);
-    uint32_t dst = 0;
-    if (live) dst = off[d] + rank;
-    __syncthreads();                                   // every lane has read its offset
-    if (live && rank == 0) off[d] += (uint32_t)__popcll(same);
-    __syncthreads();
-    if (live) { keys_out[dst] = key; if (vals_out) vals_out[dst] = val; }
+#pragma unroll
+    for (int u = 0; u < SIG_PREFETCH; ++u) {
+      const uint64_t i = base + (uint64_t)(it0 + u) * 64 + threadIdx.x;
+      const bool live = i < total;
+      const uint64_t key = kk[u];
+      const uint32_t val = vv[u];
+      const uint32_t d = live ? sig_digit(key, 8 * pass) : 0;
+      // lanes holding the same bin as this one: nine ballots, one per bit of the bin number
+      uint64_t same = __ballot(live);
+#pragma unroll
+      for (int b = 0; b < 9; ++b) {
+        const uint64_t m = __ballot(live && ((d >> b) & 1u));
+        same &= ((d >> b) & 1u) ? m : ~m;
+      }
+      const uint32_t rank = (uint32_t)__popcll(same & lane_lt);
+      uint32_t dst = 0;
+      if (live) dst = off[d] + rank;
+      __syncthreads();                                   // every lane has read its offset
+      if (live && rank == 0) off[d] += (uint32_t)__popcll(same);
+      __syncthreads();
+      if (live) { keys_out[dst] = key; if (vals_out) vals_out[dst] = val; }
+    }
   }
 }
 
