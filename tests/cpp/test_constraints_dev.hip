@@ -1,8 +1,8 @@
 // Device-side check of the 29-bit-limb constraint arithmetic (PermPoint, gate_point) against the same formulas
-// written with the 32-bit field functions.  Build and run on a GPU: hipcc --offload-arch=gfx950 -O3 -o t tools/test_constraints_dev.hip && ./t
+// written with the 32-bit field functions, stage by stage.  Built by `make -C tests/cpp`; run by tests/test_gpu_cpp_mirror.py.
 #include <cstdio>
 #include <vector>
-#include "../plonk_amd/csrc/constraints.cuh"
+#include "../../plonk_amd/csrc/constraints.cuh"
 using namespace plk;
 
 __device__ Fe dev_rnd(uint64_t s, int small) {

@@ -17,6 +17,16 @@ def test_cpp_mirror_program():
     assert r.returncode == 0 and "0 failure(s)" in r.stdout, r.stdout[-4000:] + r.stderr[-2000:]
 
 
+@pytest.mark.gpu
+def test_constraint_limb_arithmetic_on_the_device():
+    """The 29-bit-limb arithmetic of the constraint kernels against the 32-bit field functions, on the GPU, stage by stage
+    (it once differed from the host compile of the same source: the compiler narrowed multiplies of limbs it knew to be short)."""
+    exe = os.path.join(ROOT, "tests", "cpp", "test_constraints_dev")
+    assert os.path.exists(exe), "tests/cpp/test_constraints_dev missing: run `make -C tests/cpp` (or __graft_entry__.build())"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "mismatch at" not in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]
+
+
 def test_cpp_mirror_header_compiles_alone(tmp_path):
     """the header is self-contained C++17 (syntax check only: no GPU, no library needed)."""
     src = tmp_path / "t.cpp"
