@@ -44,7 +44,7 @@ def test_four_step_matches_direct_transform(prover, log_n):
 
 
 def test_four_step_2_24_roundtrip_and_agreement(prover):
-    """BASELINE config 4's size on one GPU: the four-step result equals the library's direct
+    """The 2^24-point transform on one GPU: the four-step result equals the library's direct
     three-pass transform (itself checked against the oracle) and inverts back to the input."""
     N = 1 << 24
     x = to_device(synth.random_elements(77, N), prover.device)

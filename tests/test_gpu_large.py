@@ -48,7 +48,7 @@ def test_grand_product_2_20_vs_serial_recurrence(prover, big):
 
 
 def test_round23_2_20(prover, big):
-    """BASELINE config 3.  Checks: Z against the serial recurrence; the two constraint vectors at random
+    """The n = 2^20, N = 2^22 configuration.  Checks: Z against the serial recurrence; the two constraint vectors at random
     points recomputed in big integers from the evaluated columns' definition (Horner on the coefficient
     vectors); the restriction of the gate-constraint vector to the trace domain against the direct
     row-wise formula."""

@@ -69,7 +69,7 @@ def test_transforms_vs_oracle(ctx, log_n):
 
 @pytest.mark.parametrize("log_n", [2, 6, 10, 12, 16])
 def test_each_function_vs_oracle(ctx, log_n):
-    """BASELINE config 2 is the log_n = 16 case: NTT + grand product + gate constraints vs CPU."""
+    """The log_n = 16 configuration: NTT + grand product + gate constraints vs CPU."""
     n = 1 << log_n
     c = synth.make_circuit(n, circuit_id=log_n)
     gp = pa.gate_evaluation_table_to_gate_polynomial(c.table, D(n), ctx=ctx)
