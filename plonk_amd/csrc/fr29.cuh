@@ -203,10 +203,11 @@ __device__ __forceinline__ void mont29_x2(const F9& a1, const F9& b1, const F9& 
 __host__ __device__ __forceinline__ F9 mont256(const F9& a_in, const F9& b_in) {
   F9 a = a_in, b = b_in;
 #ifdef __HIP_DEVICE_COMPILE__
-  // The compiler must not know how many bits a limb has: when both factors of a partial product are known to fit
-  // 24 bits (the top limbs of freshly cut operands, m[8]) it selects 24-bit multiplies and the result's top limb
-  // comes out wrong (seen with ROCm 7.2's clang on gfx950; the same source is right on the host and when the
-  // operands come from memory).  The empty asm statements hide the ranges and emit nothing.
+  // The compiler must not know how many bits a limb has.  With freshly cut operands in registers (top limbs known
+  // to fit 24 bits, like m[8]) ROCm 7.2's clang for gfx950 produced a wrong top limb of the result; the same source
+  // is right on the host and when the operands come from memory, and the 24-bit multiply instructions it selects
+  // for such factors are right by themselves (tools/probe_mul24.hip).  The empty asm statements hide the ranges
+  // and emit nothing; tests/cpp/test_constraints_dev.hip watches over the result.
 #pragma unroll
   for (int i = 0; i < 9; ++i) asm volatile("" : "+v"(a.l[i]), "+v"(b.l[i]));
 #endif
