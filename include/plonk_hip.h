@@ -205,6 +205,10 @@ int plk_msm_g1(plk_ctx* ctx, const uint64_t* scalars_host, size_t n, uint64_t ou
  * four wire polynomials, the parts of the quotient); results at out_xy[12 k ...].  The sums alternate between two
  * streams, so that one sum's latency-bound bucket reduction runs beside the next one's additions. */
 int plk_msm_g1_batch(plk_ctx* ctx, const uint64_t* const scalars_host[], size_t count, size_t n, uint64_t* out_xy);
+/* The sum of `count` affine points (host memory, host arithmetic, no GPU and no context needed): what adds up the
+ * partial sums when the terms of one multi-scalar multiplication are dealt to several GPUs.  Returns PLK_OK or
+ * PLK_ERR_ARG (null pointer). */
+int plk_g1_sum(const uint64_t* points_xy, size_t count, uint64_t out_xy[12]);
 
 /* ---- device entry points (same arithmetic, device pointers, asynchronous) ---------------- */
 

@@ -60,6 +60,7 @@ SIGNATURES = {
     "plk_msm_set_bases": (C.c_int, [C.c_void_p, u64p, C.c_size_t]),
     "plk_msm_g1": (C.c_int, [C.c_void_p, u64p, C.c_size_t, u64p]),
     "plk_msm_g1_batch": (C.c_int, [C.c_void_p, u64pp, C.c_size_t, C.c_size_t, u64p]),
+    "plk_g1_sum": (C.c_int, [u64p, C.c_size_t, u64p]),
     "plk_dev_msm_set_bases": (C.c_int, [C.c_void_p, u64p, C.c_size_t]),
     "plk_dev_msm_g1": (C.c_int, [C.c_void_p, C.c_void_p, u64p, C.c_size_t, u64p]),
     "plk_dev_msm_g1_batch": (C.c_int, [C.c_void_p, C.c_void_p, u64pp, C.c_size_t, C.c_size_t, u64p]),

@@ -399,6 +399,17 @@ def msm_g1(scalars: np.ndarray, ctx: Optional[Context] = None) -> np.ndarray:
     return out
 
 
+def g1_sum(points: np.ndarray) -> np.ndarray:
+    """The sum of affine G1 points `(count, 12) uint64` on the host: `(12,) uint64`."""
+    from . import _lib
+    p = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 12)
+    out = np.zeros((12,), dtype=np.uint64)
+    rc = _lib.load().plk_g1_sum(_p(p), p.shape[0], _p(out))
+    if rc != 0:
+        raise ValueError("plk_g1_sum: bad argument")
+    return out
+
+
 def msm_g1_batch(scalar_columns: Sequence[np.ndarray], ctx: Optional[Context] = None) -> np.ndarray:
     """One sum per column over the same bases (the commitments of one prover round): `(count, 12) uint64`."""
     c = _ctx(ctx)

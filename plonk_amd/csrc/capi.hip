@@ -1701,6 +1701,25 @@ int plk_msm_g1(plk_ctx* ctx, const uint64_t* scalars_host, size_t n, uint64_t ou
   return launch_msm(ctx, ctx->stream, one, 1, n, out_xy);
 }
 
+int plk_g1_sum(const uint64_t* points_xy, size_t count, uint64_t out_xy[12]) {
+  if ((!points_xy && count) || !out_xy) return PLK_ERR_ARG;
+  G1Jac acc = g1_inf();
+  for (size_t k = 0; k < count; ++k) {
+    G1Affine p;
+    for (int i = 0; i < 6; ++i) {
+      p.x.l[2 * i] = (uint32_t)points_xy[12 * k + i]; p.x.l[2 * i + 1] = (uint32_t)(points_xy[12 * k + i] >> 32);
+      p.y.l[2 * i] = (uint32_t)points_xy[12 * k + 6 + i]; p.y.l[2 * i + 1] = (uint32_t)(points_xy[12 * k + 6 + i] >> 32);
+    }
+    acc = g1_add_affine(acc, p);
+  }
+  const G1Affine r = g1_to_affine(acc);
+  for (int i = 0; i < 6; ++i) {
+    out_xy[i] = (uint64_t)r.x.l[2 * i] | ((uint64_t)r.x.l[2 * i + 1] << 32);
+    out_xy[6 + i] = (uint64_t)r.y.l[2 * i] | ((uint64_t)r.y.l[2 * i + 1] << 32);
+  }
+  return PLK_OK;
+}
+
 int plk_msm_g1_batch(plk_ctx* ctx, const uint64_t* const scalars_host[], size_t count, size_t n, uint64_t* out_xy) {
   int rc = use_device(ctx);
   if (rc) return rc;

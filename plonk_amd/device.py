@@ -109,6 +109,11 @@ class DeviceProver:
         self.ctx.check(self.lib.plk_dev_msm_g1(self.ctx.handle, self._stream(), _ptr(scalars), scalars.shape[0], out.ctypes.data_as(_lib.u64p)))
         return out
 
+    def g1_sum(self, points: np.ndarray) -> np.ndarray:
+        """The sum of affine points `(count, 12) uint64` (host arithmetic)."""
+        from .api import g1_sum
+        return g1_sum(points)
+
     def msm_batch(self, scalar_columns: Sequence[torch.Tensor]) -> np.ndarray:
         """One sum per device column over the same bases; returns `(count, 12) uint64` (host)."""
         out = np.zeros((len(scalar_columns), 12), dtype=np.uint64)

@@ -147,6 +147,17 @@ def grand_product_sharded(engine, wires: Sequence[torch.Tensor], sigma: Sequence
     return torch.cat([one] + blocks)[:n + 1].contiguous()
 
 
+def msm_sharded(engine, scalars_local: torch.Tensor, group=None):
+    """One multi-scalar multiplication with its terms dealt to the ranks: every rank has set ITS shard of the bases
+    (`engine.msm_set_bases`) and passes the matching shard of the scalars; the partial sums (96 bytes each) are
+    all-gathered and added up on the host.  Returns the affine point `(12,) uint64` on every rank."""
+    import numpy as np
+    part = np.ascontiguousarray(engine.msm(scalars_local), dtype=np.uint64)
+    t = torch.from_numpy(part.view(np.int64).copy()).to(scalars_local.device)
+    parts = _all_gather(t, group)
+    return engine.g1_sum(np.stack([p.cpu().numpy().view(np.uint64) for p in parts]))
+
+
 def assign_columns(num_columns: int, group=None) -> List[int]:
     """Columns (0..num_columns-1) this rank interpolates and extends in `round23_poly_sharded`."""
     rank, world = _world(group)

@@ -42,6 +42,19 @@ def main():
         eng.status()
         assert np.array_equal(to_host(z), co.grand_product(w_h, sg_h, cc.beta, cc.gamma)), ("sharded grand product", rows_n)
 
+    # one multi-scalar multiplication with its terms dealt to the ranks (each rank's table holds its shard of the bases)
+    import g1_oracle as g1
+    gen = np.array(g1.fq_to_mont_limbs(g1.GX) + g1.fq_to_mont_limbs(g1.GY), dtype=np.uint64)
+    terms = 1 << 12
+    lo, hi = rank * terms // world, (rank + 1) * terms // world
+    shard = eng.g1_multiples(gen, 1 + lo, hi - lo)              # (lo + 1 + i) G
+    eng.msm_set_bases(shard)
+    scal = synth.random_elements(41, terms)
+    got = pdist.msm_sharded(eng, to_device(scal[lo:hi], d))
+    total = sum(v * (i + 1) for i, v in enumerate(synth.mont_to_ints(scal))) % g1.R_ORDER
+    want = g1.mul(total, g1.G1)
+    assert [int(x) for x in got] == g1.fq_to_mont_limbs(want[0]) + g1.fq_to_mont_limbs(want[1]), "sharded msm"
+
     n, N = 1 << 10, 1 << 12
     c = synth.make_circuit(n, circuit_id=3)
     dc = eng.upload(c)

@@ -45,6 +45,17 @@ def main():
             for k2 in (0, 1, N2 - 1):
                 assert np.array_equal(blk[i, k2], full[(rank * r1 + i) + N1 * k2])
 
+    # one multi-scalar multiplication with its terms dealt to the ranks
+    import g1_oracle as g1
+    gen = np.array(g1.fq_to_mont_limbs(g1.GX) + g1.fq_to_mont_limbs(g1.GY), dtype=np.uint64)
+    terms = 8 * world
+    bases = np.stack([co.g1_msm(synth.ints_to_mont([3 * k + 1]), gen[None, :]) for k in range(terms)])
+    scal = synth.random_elements(31, terms)
+    lo, hi = rank * terms // world, (rank + 1) * terms // world
+    eng.msm_set_bases(bases[lo:hi])
+    got = pdist.msm_sharded(eng, n2t(scal[lo:hi]))
+    assert np.array_equal(got, co.g1_msm(scal, bases)), "sharded msm"
+
     # one proof over all ranks
     n, N = 32, 128
     c = synth.make_circuit(n, circuit_id=7)

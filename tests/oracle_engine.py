@@ -22,6 +22,18 @@ def n2t(a):
 class OracleEngine:
     device = torch.device("cpu")
 
+    def msm_set_bases(self, bases):
+        self._bases = np.ascontiguousarray(bases, dtype=np.uint64)
+
+    def msm(self, scalars):
+        s = t2n(scalars)
+        return co.g1_msm(s, self._bases[: s.shape[0]])
+
+    def g1_sum(self, points):
+        # every point once: a multi-scalar multiplication with all scalars one
+        p = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 12)
+        return co.g1_msm(synth.ints_to_mont([1] * p.shape[0]), p)
+
     def ntt_rows(self, mat, N, inverse=False):
         rows = [co.intt(t2n(r), N) if inverse else co.ntt(t2n(r), N) for r in mat]
         return n2t(np.stack(rows))

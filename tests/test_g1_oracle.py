@@ -80,3 +80,16 @@ def test_device_point_arithmetic_on_the_host(tmp_path):
         assert got == p, tag
         seen += 1
     assert seen == len(want)
+
+
+def test_host_point_sum_of_the_library():
+    """plk_g1_sum runs on the host (it adds up the partial sums of a sharded multi-scalar multiplication): against the oracle."""
+    import plonk_amd as pa
+    from plonk_amd.api import g1_sum
+    rng = random.Random(9)
+    ks = [rng.randrange(1, 1 << 40) for _ in range(9)]
+    pts = [g1.mul(k, g1.G1) for k in ks] + [None, g1.neg(g1.mul(ks[0], g1.G1)), g1.mul(ks[1], g1.G1)]   # infinity, an inverse, a repeat
+    got = g1_sum(np.stack([point_to_limbs(p) for p in pts]))
+    assert limbs_to_point(got) == g1.mul((sum(ks) - ks[0] + ks[1]) % g1.R_ORDER, g1.G1)
+    assert limbs_to_point(g1_sum(np.zeros((0, 12), dtype=np.uint64))) is None
+    assert limbs_to_point(g1_sum(np.stack([point_to_limbs(pts[0]), point_to_limbs(g1.neg(pts[0]))]))) is None
