@@ -119,7 +119,7 @@ struct plk_ctx {
   std::map<std::array<uint64_t, 4>, PowTable> powers;   // g -> tables of g^j (coset transforms)
   uint32_t* msm_table = nullptr;                 // affine G1 points 2^(c w) * base_i at [w * msm_nbases + i] (msm.cuh), 128 bytes each
   size_t msm_nbases = 0;
-  int msm_c = 0;                                 // window width the table was built for
+  MsmWindows msm_win = {0, 0, 0};                // how the table cuts a scalar into digits
   G1Jac* msm_sums = nullptr;                     // page-locked landing place of the sums (Jacobian, ABI form)
   size_t msm_sums_cap = 0;
   size_t gp_rows = 0;                            // rows of the grand-product range held in the workspace
@@ -913,26 +913,26 @@ void msm_free_table(plk_ctx* ctx) {
   ctx->msm_table = nullptr; ctx->msm_nbases = 0;
 }
 
-// table[w * nb + i] = 2^(c w) * bases[i] for the device array `bases` (msm.cuh); replaces the context's table
+// table[w * nb + i] = 2^(offset of window w) * bases[i] for the device array `bases` (msm.cuh); replaces the context's table
 int msm_build_table(plk_ctx* ctx, hipStream_t s, const uint64_t* bases, size_t nb) {
   msm_free_table(ctx);
   if (nb == 0) return PLK_OK;
   if (nb >= (size_t(1) << 26)) return fail(ctx, PLK_ERR_ARG, "msm: more than 2^26 bases");
-  const int c = msm_window_bits(nb), windows = (255 + c - 1) / c;
-  const size_t slots = nb * (size_t)windows;
+  const MsmWindows win = msm_windows_for(msm_window_bits(nb));
+  const size_t slots = nb * (size_t)win.windows;
   uint64_t *zs = nullptr, *prods = nullptr;
   HIP_TRY(ctx, hipMalloc((void**)&ctx->msm_table, slots * A28_WORDS * 4));
   hipError_t e = hipMalloc((void**)&zs, slots * 48);
   if (e == hipSuccess) e = hipMalloc((void**)&prods, slots * 48);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(msm_table_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, bases, (uint64_t)nb, c, windows, ctx->msm_table, zs, prods);
+    hipLaunchKernelGGL(msm_table_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, bases, (uint64_t)nb, win, ctx->msm_table, zs, prods);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   if (zs) (void)hipFree(zs);
   if (prods) (void)hipFree(prods);
   if (e != hipSuccess) { msm_free_table(ctx); HIP_TRY(ctx, e); }
-  ctx->msm_nbases = nb; ctx->msm_c = c;
+  ctx->msm_nbases = nb; ctx->msm_win = win;
   return PLK_OK;
 }
 
@@ -941,11 +941,15 @@ int msm_build_table(plk_ctx* ctx, hipStream_t s, const uint64_t* bases, size_t n
 // `slot` names the workspace: sums in flight at the same time on different streams need different slots.
 int msm_enqueue(plk_ctx* ctx, hipStream_t s, const uint64_t* scalars, size_t n, int slot, G1Jac* host_sum) {
   const std::string ws = "msm" + std::to_string(slot);
-  const int c = ctx->msm_c, windows = (255 + c - 1) / c;
+  const MsmWindows win = ctx->msm_win;
+  const int c = win.c, windows = win.windows;
   const uint64_t total = (uint64_t)n * windows, nbuckets = 1ull << c;
   // lanes per bucket: about 32 entries each (measured flat between 20 and 45; their partial sums are added up by a
   // second kernel whose cost grows with the lane count)
-  const uint32_t lanes = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, (total >> c) / 32));
+  uint32_t lanes = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, (total >> c) / 32));
+  // a small sum does not fill the GPU (about 2 * 10^5 lanes at three waves per SIMD): its time is the longest chain of
+  // additions, so the runs are split further while lanes are free
+  while (lanes < 64 && nbuckets * lanes * 2 <= 196608 && (total >> c) / (lanes * 2) >= 6) lanes *= 2;
   int rc;
   PairSort ps;
   if ((rc = pair_sort_alloc(ctx, s, ws, total, &ps, false))) return rc;     // the keys carry the table index
@@ -960,8 +964,8 @@ int msm_enqueue(plk_ctx* ctx, hipStream_t s, const uint64_t* scalars, size_t n, 
   HIP_TRY(ctx, hipMemsetAsync(pf, 0, 2 * nbuckets * 4, s));
   {
     ProfScope p(ctx, s, "msm_digits_kernel", 32.0 * (double)n);
-    hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scalars, (uint64_t)n, (uint64_t)ctx->msm_nbases, c,
-                       windows, ps.pairs.keys[0], ps.or_bits);
+    hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scalars, (uint64_t)n, (uint64_t)ctx->msm_nbases, win,
+                       ps.pairs.keys[0], ps.or_bits);
     HIP_TRY(ctx, hipGetLastError());
   }
   if ((rc = pair_sort_run(ctx, s, ps, 0.0))) return rc;

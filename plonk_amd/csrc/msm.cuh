@@ -3,7 +3,7 @@
 //
 // The reference only imports `ark_poly_commit::kzg10` (src/main.rs:9); commitments are listed as not
 // implemented (README.md:15-17).  The bases are fixed per circuit size, so when they are set the table
-// T[w][i] = 2^(c w) * P_i (affine, W = ceil(255 / c) windows) is built once; with it digit d of window w of
+// T[w][i] = 2^(offset of window w) * P_i (affine, W = ceil(255 / c) windows of c or c - 1 bits) is built once; with it digit d of window w of
 // scalar i contributes d * T[w][i], and ALL windows share one set of 2^c buckets:
 //   1. every scalar (Montgomery form, as ark-ff keeps it) is made canonical and cut into W digits of c bits;
 //      digit d of window w gives the 64-bit key (w * nb + i) << 16 | d;
@@ -25,23 +25,39 @@ namespace plk {
 constexpr int MSM_FOLD_THREADS = 512;
 constexpr int MSM_MAX_WINDOW_BITS = 16;   // a fold handles a matrix of at most 256 x 256 buckets
 
+// The 255 scalar bits are cut into `windows` digits of nearly equal width: the first `wide` of them have c bits, the
+// others c - 1 (a narrow last window - 255 mod c bits - would put its digits into a few buckets with very long runs).
+struct MsmWindows {
+  int c, windows, wide;
+  __host__ __device__ __forceinline__ int width(int w) const { return w < wide ? c : c - 1; }
+  __host__ __device__ __forceinline__ int offset(int w) const { return w * (c - 1) + (w < wide ? w : wide); }
+};
+__host__ __device__ inline MsmWindows msm_windows_for(int max_bits) {
+  MsmWindows r;
+  r.windows = (255 + max_bits - 1) / max_bits;
+  const int base = 255 / r.windows, rem = 255 % r.windows;
+  r.c = base + (rem ? 1 : 0);
+  r.wide = rem ? rem : r.windows;
+  return r;
+}
+
 constexpr int MSM_KEY_DIGIT_BITS = 16;    // a pair is one 64-bit key: (table entry << 16) | digit; the sort looks at the digit only
 static_assert(MSM_MAX_WINDOW_BITS <= MSM_KEY_DIGIT_BITS, "a digit must fit the low bits of a key");
 
 // step 1: key[w * n + i] = (table entry w * nb + i) << 16 | digit w of scalar i; also the OR of all digits (the sort
 // skips the byte passes it shows to be zero, which leaves the upper bits in their stable order)
-__global__ __launch_bounds__(256) void msm_digits_kernel(const uint64_t* scalars, uint64_t n, uint64_t nb, int c, int windows,
+__global__ __launch_bounds__(256) void msm_digits_kernel(const uint64_t* scalars, uint64_t n, uint64_t nb, MsmWindows win,
                                                          uint64_t* keys, uint64_t* or_bits) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   uint64_t seen = 0;
   if (i < n) {
     Fe one = fe_zero(); one.l[0] = 1;
     const Fe s = fe_mul(fe_load(scalars, i), one);          // out of Montgomery form: the integer below p
-    for (int w = 0; w < windows; ++w) {
-      const int bit = w * c, limb = bit >> 5, off = bit & 31;
+    for (int w = 0; w < win.windows; ++w) {
+      const int bit = win.offset(w), limb = bit >> 5, off = bit & 31;
       uint64_t chunk = s.l[limb];
       if (limb + 1 < 8) chunk |= (uint64_t)s.l[limb + 1] << 32;
-      const uint64_t d = (chunk >> off) & ((1ull << c) - 1);
+      const uint64_t d = (chunk >> off) & ((1ull << win.width(w)) - 1);
       keys[(uint64_t)w * n + i] = (((uint64_t)w * nb + i) << MSM_KEY_DIGIT_BITS) | d;    // digit 0 lands in bucket 0, which is never read
       seen |= d;
     }
@@ -138,13 +154,14 @@ __global__ __launch_bounds__(MSM_FOLD_THREADS) void msm_fold_kernel(const uint32
   }
 }
 
-// Table set-up, one thread per base: table[w * nb + i] = 2^(c w) * P_i as affine points in the working form of
+// Table set-up, one thread per base: table[w * nb + i] = 2^(offset of window w) * P_i as affine points in the working form of
 // fq28.cuh (32 words each), w < windows.  Computed in the ABI form: the Jacobian X, Y are parked in the table slot
 // itself and Z in `zs`; the running products of the Z's in `prods` turn the W conversions to affine into one
 // inversion per base.  (An infinite base gives W infinite entries; G1 has odd order, so doubling a finite point
 // never reaches infinity.)
-__global__ __launch_bounds__(256) void msm_table_kernel(const uint64_t* bases, uint64_t nb, int c, int windows, uint32_t* table,
+__global__ __launch_bounds__(256) void msm_table_kernel(const uint64_t* bases, uint64_t nb, MsmWindows win, uint32_t* table,
                                                         uint64_t* zs, uint64_t* prods) {
+  const int windows = win.windows;
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= nb) return;
   const G1Affine a = g1_load_affine(bases, i);
@@ -156,7 +173,7 @@ __global__ __launch_bounds__(256) void msm_table_kernel(const uint64_t* bases, u
   G1Jac p = g1_from_affine(a);
   Fq run = fq_one();
   for (int w = 0; w < windows; ++w) {
-    if (w) for (int d = 0; d < c; ++d) p = g1_double(p);
+    if (w) for (int d = 0; d < win.width(w - 1); ++d) p = g1_double(p);
     const uint64_t slot = (uint64_t)w * nb + i;
     uint64_t* park = reinterpret_cast<uint64_t*>(table + slot * A28_WORDS);     // 128 bytes: room for two 48-byte coordinates
     fq_store(park, 0, p.x);
