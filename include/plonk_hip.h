@@ -197,8 +197,8 @@ int plk_quotient(plk_ctx* ctx, const uint64_t* const* numerators, size_t count, 
  *  - plk_dev_g1_multiples writes (first + i) * base, i < count, as affine points to device memory
  *    (test and benchmark set-up: a table whose discrete logarithms are known).
  * The window width follows the number of BASES, so a call with far fewer scalars than bases is correct but
- * slower than after a set_bases of that size.  Run time depends on the scalars only through how evenly their
- * digits spread over the 2^c buckets: a few lanes add up each bucket, so n equal scalars serialise. */
+ * slower than after a set_bases of that size.  Every bucket gets lanes in proportion to the number of digits that
+ * fall into it, so scalars that crowd into a few buckets (all equal, all small) cost about the same as random ones. */
 int plk_msm_set_bases(plk_ctx* ctx, const uint64_t* bases_host, size_t n);
 int plk_msm_g1(plk_ctx* ctx, const uint64_t* scalars_host, size_t n, uint64_t out_xy[12]);
 /* `count` sums over the same bases, scalars[k] holding n elements each: the commitments of one prover round (the

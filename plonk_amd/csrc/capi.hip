@@ -950,6 +950,9 @@ int msm_enqueue(plk_ctx* ctx, hipStream_t s, const uint64_t* scalars, size_t n, 
   // a small sum does not fill the GPU (about 2 * 10^5 lanes at three waves per SIMD): its time is the longest chain of
   // additions, so the runs are split further while lanes are free
   while (lanes < 64 && nbuckets * lanes * 2 <= 196608 && (total >> c) / (lanes * 2) >= 6) lanes *= 2;
+  // that was the average bucket; every bucket gets one lane per `per_lane` entries of its own run (msm_lanes_kernel)
+  const uint32_t per_lane = (uint32_t)std::max<uint64_t>(1, ((total >> c) + lanes - 1) / lanes);
+  const uint64_t lane_bound = total / per_lane + nbuckets;          // sum of ceil(run / per_lane) over the buckets, at most
   int rc;
   PairSort ps;
   if ((rc = pair_sort_alloc(ctx, s, ws, total, &ps, false))) return rc;     // the keys carry the table index
@@ -957,8 +960,10 @@ int msm_enqueue(plk_ctx* ctx, hipStream_t s, const uint64_t* scalars, size_t n, 
   constexpr size_t point_bytes = J28_WORDS * 4;
   if ((rc = ws_get(ctx, ws + "_bounds", 2 * nbuckets * 4, &pf))) return rc;
   if ((rc = ws_get(ctx, ws + "_buckets", nbuckets * point_bytes, &pb))) return rc;
-  void* pp_part;
-  if ((rc = ws_get(ctx, ws + "_partials", nbuckets * lanes * point_bytes, &pp_part))) return rc;
+  void *pp_part, *po;
+  if ((rc = ws_get(ctx, ws + "_partials", lane_bound * point_bytes, &pp_part))) return rc;
+  if ((rc = ws_get(ctx, ws + "_lanes", (nbuckets + 1) * 4, &po))) return rc;
+  const uint32_t* off = (const uint32_t*)po;
   if ((rc = ws_get(ctx, ws + "_fold", 2 * 256 * point_bytes + 2 * 144, &pa))) return rc;
   uint32_t* first = (uint32_t*)pf; uint32_t* last = first + nbuckets;
   HIP_TRY(ctx, hipMemsetAsync(pf, 0, 2 * nbuckets * 4, s));
@@ -974,15 +979,21 @@ int msm_enqueue(plk_ctx* ctx, hipStream_t s, const uint64_t* scalars, size_t n, 
     hipLaunchKernelGGL(msm_bounds_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ps.pairs, (const uint64_t*)ps.or_bits, total, first, last);
   }
   {
-    ProfScope p(ctx, s, "msm_bucket_sum_kernel", 128.0 * (double)total);   // one affine table entry per pair
-    hipLaunchKernelGGL(msm_bucket_sum_kernel, dim3((unsigned)((nbuckets * lanes + 255) / 256)), dim3(256), 0, s, ps.pairs,
-                       (const uint64_t*)ps.or_bits, (const uint32_t*)first, (const uint32_t*)last, nbuckets, lanes, (const uint32_t*)ctx->msm_table,
-                       (uint32_t*)(lanes > 1 ? pp_part : pb));
+    ProfScope p(ctx, s, "msm_lanes_kernel", 8.0 * (double)nbuckets);
+    hipLaunchKernelGGL(msm_lanes_kernel, dim3(1), dim3(SIG_SCAN_THREADS), 0, s, (const uint32_t*)first, (const uint32_t*)last, (uint32_t)nbuckets, per_lane,
+                       (uint32_t*)po);
   }
-  if (lanes > 1) {
-    ProfScope p(ctx, s, "msm_bucket_combine_kernel", (double)point_bytes * (double)(nbuckets * lanes));
-    hipLaunchKernelGGL(msm_bucket_combine_kernel, dim3((unsigned)((2 * nbuckets + 255) / 256)), dim3(256), 0, s, (const uint32_t*)pp_part, nbuckets, lanes,
-                       (uint32_t*)pb);
+  {
+    ProfScope p(ctx, s, "msm_bucket_sum_kernel", 128.0 * (double)total);   // one affine table entry per pair
+    hipLaunchKernelGGL(msm_bucket_sum_kernel, dim3((unsigned)((lane_bound + 255) / 256)), dim3(256), 0, s, ps.pairs, (const uint64_t*)ps.or_bits,
+                       (const uint32_t*)first, (const uint32_t*)last, (uint32_t)nbuckets, off, (const uint32_t*)ctx->msm_table, (uint32_t*)pp_part);
+  }
+  {
+    ProfScope p(ctx, s, "msm_bucket_combine_kernel", (double)point_bytes * (double)lane_bound);
+    hipLaunchKernelGGL(msm_bucket_combine_kernel, dim3((unsigned)((2 * nbuckets + 255) / 256)), dim3(256), 0, s, (const uint32_t*)pp_part, off,
+                       (uint32_t)nbuckets, (uint32_t*)pb);
+    hipLaunchKernelGGL(msm_bucket_combine_big_kernel, dim3((unsigned)std::min<uint64_t>(64, (nbuckets + MSM_BIG_THREADS - 1) / MSM_BIG_THREADS)),
+                       dim3(MSM_BIG_THREADS), 0, s, (const uint32_t*)pp_part, off, (uint32_t)nbuckets, (uint32_t*)pb);
   }
   // folds: 2^c points -> 2^ceil(c/2) -> ... -> 2; then sum_d d * B_d = B_1
   const uint32_t* in = (const uint32_t*)pb;

@@ -81,9 +81,15 @@ __global__ __launch_bounds__(256) void msm_bounds_kernel(SigPairs pairs, const u
   if (p + 1 == total || (keys[p + 1] & mask) != d) last[d] = (uint32_t)p + 1;
 }
 
-// step 3: bucket b = sum of the table entries of its run; `lanes` adjacent lanes share a bucket (entry j, j + lanes, ...
-// each), so that long runs do not serialise on one lane, and a second kernel adds their partial sums up.  (Two kernels
-// because the mixed addition alone fits three waves per SIMD; with the full addition beside it two.)
+// step 3: bucket b = sum of the table entries of its run.  A run is shared by ceil(length / per_lane) lanes (entry j,
+// j + lanes, ... each), whatever its length: digits that crowd into a few buckets (equal scalars, small scalars)
+// get as many lanes as they have entries for, and an empty bucket gets none.  Three kernels: the lanes of every
+// bucket and their prefix sums; the additions (a kernel of its own because the mixed addition alone fits three waves
+// per SIMD, with the full addition beside it two); and the sum of each bucket's partial sums - two lanes per bucket,
+// or a whole workgroup for a bucket with more than MSM_BIG_BUCKET of them.
+constexpr uint32_t MSM_BIG_BUCKET = 64;
+constexpr int MSM_BIG_THREADS = 256;
+
 __device__ __forceinline__ F14 f14_shfl_down(const F14& a, int delta) {
   F14 r;
 #pragma unroll
@@ -91,38 +97,93 @@ __device__ __forceinline__ F14 f14_shfl_down(const F14& a, int delta) {
   return r;
 }
 
+// off[b] = number of lanes of the buckets before b; off[nbuckets] = all lanes.  One workgroup.
+__global__ __launch_bounds__(SIG_SCAN_THREADS) void msm_lanes_kernel(const uint32_t* first, const uint32_t* last, uint32_t nbuckets,
+                                                                     uint32_t per_lane, uint32_t* off) {
+  __shared__ uint32_t lds[SIG_SCAN_THREADS / 64];
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < nbuckets; base += SIG_SCAN_THREADS) {   // uniform trip count
+    const uint32_t b = base + threadIdx.x;
+    const uint32_t v = b < nbuckets ? (last[b] - first[b] + per_lane - 1) / per_lane : 0;
+    uint32_t total;
+    const uint32_t ex = sig_block_exclusive(v, lds, &total);
+    if (b < nbuckets) off[b] = carry + ex;
+    carry += total;
+  }
+  if (threadIdx.x == 0) off[nbuckets] = carry;
+}
+
+// one lane: partials[t] = sum of its share of its bucket's run (the grid is an upper bound of the lane count)
 __global__ __launch_bounds__(256, 3) void msm_bucket_sum_kernel(SigPairs pairs, const uint64_t* or_bits, const uint32_t* first,
-                                                                const uint32_t* last, uint64_t nbuckets, uint32_t lanes, const uint32_t* table,
-                                                                uint32_t* partials) {
+                                                                const uint32_t* last, uint32_t nbuckets, const uint32_t* off,
+                                                                const uint32_t* table, uint32_t* partials) {
   const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  const uint64_t b = gid / lanes;
-  if (b >= nbuckets) return;
-  const uint32_t j = (uint32_t)(gid - b * lanes);
+  if (gid >= off[nbuckets]) return;
+  const uint32_t t = (uint32_t)gid;
+  uint32_t lo = 0, hi = nbuckets;                     // off[lo] <= t < off[hi]: the bucket is the b with off[b] <= t < off[b + 1]
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (off[mid] <= t) lo = mid; else hi = mid;
+  }
+  const uint32_t b = lo, lanes = off[b + 1] - off[b], j = t - off[b];
   const uint64_t* keys = pairs.keys[sig_buffer_before(or_bits, 8)];
   J28 acc = j28_inf();
   const uint32_t end = last[b];
   for (uint32_t p = first[b] + j; p < end; p += lanes) acc = j28_add_affine<true>(acc, a28_load(table, keys[p] >> MSM_KEY_DIGIT_BITS));
-  j28_store(partials, gid, acc);
+  j28_store(partials, t, acc);
 }
 
-// bucket b = sum of its `lanes` >= 2 partial sums: two lanes per bucket add up half of them each, one after the
-// other, and combine by a shuffle (a tree over all the lanes would leave most of them adding nothing)
-__global__ __launch_bounds__(256) void msm_bucket_combine_kernel(const uint32_t* partials, uint64_t nbuckets, uint32_t lanes, uint32_t* buckets) {
+// bucket b = sum of its partial sums, for the buckets with at most MSM_BIG_BUCKET of them: two lanes per bucket add
+// up half of them each, one after the other, and combine by a shuffle
+__global__ __launch_bounds__(256) void msm_bucket_combine_kernel(const uint32_t* partials, const uint32_t* off, uint32_t nbuckets, uint32_t* buckets) {
   const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;      // the grid covers whole waves: the shuffle needs every lane
-  const uint64_t b = gid >> 1;
-  const uint32_t h = (uint32_t)gid & 1, half = (lanes + 1) / 2;
+  const uint32_t b = (uint32_t)(gid >> 1), h = (uint32_t)gid & 1;
+  const bool in_range = b < nbuckets;
+  const uint32_t at = in_range ? off[b] : 0, lanes = in_range ? off[b + 1] - at : 0;
+  const bool mine_to_do = in_range && lanes <= MSM_BIG_BUCKET;
   J28 part = j28_inf();
-  if (b < nbuckets) {
-    const uint64_t at = b * lanes + (uint64_t)h * half;
-    const uint32_t mine = h ? lanes - half : half;                    // >= 1: lanes >= 2
-    part = j28_load(partials, at);
-    for (uint32_t k = 1; k < mine; ++k) part = j28_add_inl(part, j28_load(partials, at + k));
+  if (mine_to_do) {
+    const uint32_t half = (lanes + 1) / 2, from = h ? half : 0, count = h ? lanes - half : half;
+    for (uint32_t k = 0; k < count; ++k) part = k ? j28_add_inl(part, j28_load(partials, at + from + k)) : j28_load(partials, at + from);
   }
   J28 other;
   other.x = f14_shfl_down(part.x, 1); other.y = f14_shfl_down(part.y, 1); other.z = f14_shfl_down(part.z, 1);
   if (h) other.z = f14_zero();
   part = j28_add_inl(part, other);
-  if (b < nbuckets && h == 0) j28_store(buckets, b, part);
+  if (mine_to_do && h == 0) j28_store(buckets, b, part);
+}
+
+// the same for the buckets with more partial sums than that, a workgroup per bucket: every workgroup looks through its
+// share of the buckets 256 at a time and adds up the few it finds (strided sums per thread, then an LDS tree)
+__global__ __launch_bounds__(MSM_BIG_THREADS) void msm_bucket_combine_big_kernel(const uint32_t* partials, const uint32_t* off, uint32_t nbuckets,
+                                                                                uint32_t* buckets) {
+  __shared__ uint32_t lds[MSM_BIG_THREADS * J28_WORDS];
+  __shared__ uint32_t big[MSM_BIG_THREADS];
+  __shared__ uint32_t nbig;
+  for (uint32_t base = blockIdx.x * MSM_BIG_THREADS; base < nbuckets; base += gridDim.x * MSM_BIG_THREADS) {   // uniform per workgroup
+    if (threadIdx.x == 0) nbig = 0;
+    __syncthreads();
+    const uint32_t mine = base + threadIdx.x;
+    if (mine < nbuckets && off[mine + 1] - off[mine] > MSM_BIG_BUCKET) big[atomicAdd(&nbig, 1u)] = mine;
+    __syncthreads();
+    const uint32_t found = nbig;
+    for (uint32_t q = 0; q < found; ++q) {
+      const uint32_t b = big[q], at = off[b], lanes = off[b + 1] - at;
+      J28 acc = j28_inf();
+      for (uint32_t k = threadIdx.x; k < lanes; k += MSM_BIG_THREADS) acc = j28_add_inl(acc, j28_load(partials, at + k));
+      j28_store(lds, threadIdx.x, acc);
+      __syncthreads();
+      for (uint32_t step = MSM_BIG_THREADS / 2; step >= 1; step >>= 1) {
+        if (threadIdx.x < step) {
+          acc = j28_add_inl(acc, j28_load(lds, threadIdx.x + step));
+          j28_store(lds, threadIdx.x, acc);
+        }
+        __syncthreads();
+      }
+      if (threadIdx.x == 0) j28_store(buckets, b, acc);
+    }
+    __syncthreads();
+  }
 }
 
 // step 4, one fold: in = 2^c points B_d, d = hi * cols + lo with cols = 2^floor(c/2), rows = 2^ceil(c/2);

@@ -110,3 +110,28 @@ def test_msm_batch(prover, ctx):
     assert prover.msm_batch([]).shape == (0, 12)
     pa.msm_set_bases(to_host(bases), ctx=ctx)
     assert np.array_equal(pa.msm_g1_batch(cols, ctx=ctx), single)
+
+
+@pytest.mark.parametrize("log_n", [10, 14, 17])
+def test_msm_crowded_buckets(prover, log_n):
+    """Scalars whose digits crowd into a few buckets (all equal, all small, mostly zero): every bucket gets lanes in
+    proportion to its run, and a run of more than 64 lanes' worth is added up by a whole workgroup."""
+    import time
+    n = 1 << log_n
+    prover.msm_set_bases(prover.g1_multiples(G, 1, n))
+    rng = np.random.default_rng(log_n)
+    cases = {
+        "all ones": [1] * n,
+        "all r - 1": [g1.R_ORDER - 1] * n,
+        "below 2^10": [int(v) for v in rng.integers(0, 1 << 10, n)],
+        "one in sixteen": [int(v) if k % 16 == 0 else 0 for k, v in enumerate(rng.integers(1, 1 << 62, n))],
+        "two values": [0x1234567 if k % 3 else (1 << 200) + 5 for k in range(n)],
+    }
+    for name, ints in cases.items():
+        s = to_device(synth.ints_to_mont(ints), prover.device)
+        t0 = time.perf_counter()
+        got = prover.msm(s)
+        dt = time.perf_counter() - t0
+        total = sum(v * (i + 1) for i, v in enumerate(ints)) % g1.R_ORDER
+        assert limbs_to_point(got) == (g1.mul(total, g1.G1) if total else None), name
+        assert dt < 0.5, (name, dt)           # one lane per bucket would take seconds at the larger sizes
