@@ -64,9 +64,12 @@ long long plk_last_error_row(const plk_ctx* ctx);
 void plk_field_constants(uint64_t modulus[4], uint64_t one[4], uint64_t r2[4]);
 
 /* Page-locked host memory for the columns passed to the host entry points.  They accept any host
- * pointer; buffers from plk_host_alloc are copied to and from the GPU by DMA at PCIe speed, others
- * go through the runtime's staging copies (measured 3-4x slower).  No counterpart in the reference
- * (a Rust caller would back its Vec<F> with these through a custom allocator). */
+ * pointer; buffers from plk_host_alloc are copied to and from the GPU by DMA at PCIe speed.  Ordinary
+ * (pageable) buffers of 8 MiB and more are copied by a pool of up to ten threads that the context starts
+ * at the first such copy and plk_ctx_destroy joins (each stages 4 MiB chunks through page-locked slots of
+ * its own): about 1.3x the time of the page-locked path for a whole plk_round23 call, where the runtime's
+ * own staging made it 2.3x.  No counterpart in the reference (a Rust caller would back its Vec<F> with
+ * plk_host_alloc through a custom allocator). */
 int plk_host_alloc(plk_ctx* ctx, size_t bytes, void** out);
 void plk_host_free(plk_ctx* ctx, void* p);
 
