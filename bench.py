@@ -352,7 +352,8 @@ def main():
         from plonk_amd.device import DeviceCircuit
         dc2 = DeviceCircuit(dc.n, dc.wires, {k: v for k, v in dc.selectors.items() if k not in ("Int", "Bool")}, dc.sigma, dc.beta, dc.gamma)
         out2 = (prover.empty(n + 1), prover.empty(N), prover.empty(N))
-        prover.round23(dc2, N, out=out2)
+        for _ in range(max(1, args.warmup)):
+            prover.round23(dc2, N, out=out2)
         same = all(bool(torch.equal(a, b)) for a, b in zip(out, out2))
         steps2 = max(3, args.steps // 2)
         torch.cuda.synchronize()
