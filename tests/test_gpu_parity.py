@@ -158,3 +158,44 @@ def test_extend4_equals_padded_transform(prover, log_n):
         assert np.array_equal(to_host(g), to_host(w))
     ref = co.ntt(co.intt(c.table.input1, n), 4 * n)
     assert np.array_equal(to_host(got[0]), ref)
+
+
+def test_pointwise_kernels_at_extreme_values(prover):
+    """The constraint kernels keep sums and differences lazy (values of several p between products): columns made of
+    0, 1, p - 1, p - 2, (p - 1) / 2 and random elements, every combination the period lets meet, against big integers."""
+    import plonk_oracle as po
+    from plonk_amd.device import to_device, to_host
+    p, N = po.P, 1 << 10
+    special = [0, 1, p - 1, p - 2, (p - 1) // 2, 2, p - 3]
+    rng = np.random.default_rng(5)
+
+    def column(period, phase):
+        vals = []
+        for i in range(N):
+            k = (i // period + phase) % (len(special) + 1)
+            vals.append(special[k] if k < len(special) else int(rng.integers(0, 1 << 62)) ** 4 % p)
+        return vals
+
+    wires = [column(1, 0), column(8, 3), column(64, 5), column(3, 1)]
+    sels = [column(5, k) for k in range(9)]
+    sigma = [column(7, k + 2) for k in range(4)]
+    z = column(11, 4)
+    beta, gamma = p - 1, p - 2
+    dev = lambda ints: to_device(synth.ints_to_mont(ints), prover.device)
+    kinds = pa.AST_KINDS
+    got = synth.mont_to_ints(to_host(prover.gate_constraint_eval([dev(w) for w in wires], {k: dev(s) for k, s in zip(kinds, sels)}, N)))
+    a, b, c, o = wires
+    for i in range(N):
+        terms = [0, 0, o[i] - (a[i] + b[i]), o[i] - (a[i] - b[i]), o[i] - a[i] * b[i], o[i] * b[i] - a[i], o[i] * (a[i] - b[i]),
+                 o[i] + a[i] - 1, o[i] - (a[i] * b[i] + (1 - a[i]) * c[i])]
+        assert got[i] == sum(s[i] * t for s, t in zip(sels, terms)) % p, ("gate", i)
+    bm, gm = synth.ints_to_mont([beta])[0], synth.ints_to_mont([gamma])[0]
+    for shift in (1, 4):
+        got = synth.mont_to_ints(to_host(prover.perm_constraint_eval(dev(z), [dev(s) for s in sigma], [dev(w) for w in wires], N, bm, gm,
+                                                                     z_shift=shift)))
+        for i in range(N):
+            lhs = rhs = 1
+            for k in range(4):
+                lhs = lhs * (wires[k][i] + beta * i + gamma) % p
+                rhs = rhs * (wires[k][i] + beta * sigma[k][i] + gamma) % p
+            assert got[i] == (z[(i + shift) % N] * lhs - z[i] * rhs) % p, ("perm", shift, i)
