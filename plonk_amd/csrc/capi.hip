@@ -849,9 +849,11 @@ int pair_sort_alloc(plk_ctx* ctx, hipStream_t s, const std::string& prefix, uint
   return PLK_OK;
 }
 
-int pair_sort_run(plk_ctx* ctx, hipStream_t s, const PairSort& ps, double alg_per_pass) {
-  // eight digit passes are enqueued; a pass whose digit is zero in every key returns at once
-  for (int pass = 0; pass < 8; ++pass) {
+// `passes`: the byte passes to enqueue, from the lowest; a caller who knows that the bytes above are zero in every
+// used key (so that their passes would return at once) spares their launches
+int pair_sort_run(plk_ctx* ctx, hipStream_t s, const PairSort& ps, double alg_per_pass, int passes = 8) {
+  // a pass whose digit is zero in every key returns at once
+  for (int pass = 0; pass < passes; ++pass) {
     const std::string ptag = "/p" + std::to_string(pass);
     { ProfScope p(ctx, s, "sig_hist_kernel" + ptag, alg_per_pass / 3);
       hipLaunchKernelGGL(sig_hist_kernel, dim3(ps.waves), dim3(64), 0, s, ps.pairs, ps.total, pass, (const uint64_t*)ps.or_bits, ps.hist, ps.waves); }
@@ -973,7 +975,7 @@ int msm_enqueue(plk_ctx* ctx, hipStream_t s, const uint64_t* scalars, size_t n, 
                        ps.pairs.keys[0], ps.or_bits);
     HIP_TRY(ctx, hipGetLastError());
   }
-  if ((rc = pair_sort_run(ctx, s, ps, 0.0))) return rc;
+  if ((rc = pair_sort_run(ctx, s, ps, 0.0, (MSM_KEY_DIGIT_BITS + 7) / 8))) return rc;     // the OR holds digits only
   {
     ProfScope p(ctx, s, "msm_bounds_kernel", 0.0);
     hipLaunchKernelGGL(msm_bounds_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ps.pairs, (const uint64_t*)ps.or_bits, total, first, last);
@@ -1011,6 +1013,50 @@ int msm_enqueue(plk_ctx* ctx, hipStream_t s, const uint64_t* scalars, size_t n, 
   return PLK_OK;
 }
 
+// Jacobian -> affine on the host with 64-bit limbs (the 32-bit code of g1.cuh, written for the GPU, takes ~0.15 ms
+// for the inversion on a host core; this takes ~0.02 ms).  Same Montgomery form: pairs of 32-bit limbs.
+struct Fq64 { uint64_t l[6]; };
+inline Fq64 fq64_from(const Fq& a) { Fq64 r; for (int i = 0; i < 6; ++i) r.l[i] = (uint64_t)a.l[2 * i] | ((uint64_t)a.l[2 * i + 1] << 32); return r; }
+inline Fq fq64_to(const Fq64& a) { Fq r; for (int i = 0; i < 6; ++i) { r.l[2 * i] = (uint32_t)a.l[i]; r.l[2 * i + 1] = (uint32_t)(a.l[i] >> 32); } return r; }
+inline Fq64 fq64_mul(const Fq64& a, const Fq64& b) {
+  static const Fq64 q = [] { Fq t; for (int i = 0; i < 12; ++i) t.l[i] = FqP::P[i]; return fq64_from(t); }();
+  static const uint64_t inv = ((uint64_t)0x89f3fffcu << 32) | FqP::INV32;      // -1 / q mod 2^64 (checked below)
+  typedef unsigned __int128 u128;
+  uint64_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 6; ++i) {
+    u128 c = 0;
+    for (int j = 0; j < 6; ++j) { c += (u128)a.l[j] * b.l[i] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
+    c += t[6]; t[6] = (uint64_t)c; t[7] = (uint64_t)(c >> 64);
+    const uint64_t m = t[0] * inv;
+    c = ((u128)m * q.l[0] + t[0]) >> 64;
+    for (int j = 1; j < 6; ++j) { c += (u128)m * q.l[j] + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
+    c += t[6]; t[5] = (uint64_t)c; t[6] = t[7] + (uint64_t)(c >> 64);
+  }
+  // t < 2q: one conditional subtraction
+  uint64_t d[6]; u128 bo = 0;
+  for (int j = 0; j < 6; ++j) { const u128 x = (u128)t[j] - q.l[j] - (uint64_t)bo; d[j] = (uint64_t)x; bo = (x >> 64) & 1; }
+  Fq64 r;
+  for (int j = 0; j < 6; ++j) r.l[j] = bo ? t[j] : d[j];
+  return r;
+}
+G1Affine g1_to_affine_host(const G1Jac& p) {
+  G1Affine r;
+  if (g1_is_inf(p)) { r.x = fq_zero(); r.y = fq_zero(); return r; }
+  const Fq64 z = fq64_from(p.z);
+  Fq64 acc = fq64_from(fq_one());
+  uint32_t e[12];
+  for (int i = 0; i < 12; ++i) e[i] = FqP::P[i];
+  e[0] -= 2;                                     // z^(q - 2) = 1 / z
+  for (int bit = 380; bit >= 0; --bit) {
+    acc = fq64_mul(acc, acc);
+    if ((e[bit >> 5] >> (bit & 31)) & 1) acc = fq64_mul(acc, z);
+  }
+  const Fq64 zi2 = fq64_mul(acc, acc);
+  r.x = fq64_to(fq64_mul(fq64_from(p.x), zi2));
+  r.y = fq64_to(fq64_mul(fq64_from(p.y), fq64_mul(zi2, acc)));
+  return r;
+}
+
 // `count` sums over the same bases, scalars[k] on the device with n elements each; the affine results (x, y; (0, 0) =
 // infinity) go to out_xy[12 k ...] in host memory.  Waits for the stream.  With more than one sum they alternate
 // between s and the context's side stream, so that one sum's latency-bound bucket reduction runs beside the next
@@ -1044,7 +1090,7 @@ int launch_msm(plk_ctx* ctx, hipStream_t s, const uint64_t* const* scalars, size
   if (rc) return rc;
   HIP_TRY(ctx, hipStreamSynchronize(s));
   for (size_t k = 0; k < count; ++k) {
-    const G1Affine r = g1_to_affine(ctx->msm_sums[k]);      // one base-field inversion each, on the host
+    const G1Affine r = g1_to_affine_host(ctx->msm_sums[k]);      // one base-field inversion each, on the host
     for (int i = 0; i < 6; ++i) {
       out_xy[12 * k + i] = (uint64_t)r.x.l[2 * i] | ((uint64_t)r.x.l[2 * i + 1] << 32);
       out_xy[12 * k + 6 + i] = (uint64_t)r.y.l[2 * i] | ((uint64_t)r.y.l[2 * i + 1] << 32);
@@ -1727,7 +1773,7 @@ int plk_g1_sum(const uint64_t* points_xy, size_t count, uint64_t out_xy[12]) {
     }
     acc = g1_add_affine(acc, p);
   }
-  const G1Affine r = g1_to_affine(acc);
+  const G1Affine r = g1_to_affine_host(acc);
   for (int i = 0; i < 6; ++i) {
     out_xy[i] = (uint64_t)r.x.l[2 * i] | ((uint64_t)r.x.l[2 * i + 1] << 32);
     out_xy[6 + i] = (uint64_t)r.y.l[2 * i] | ((uint64_t)r.y.l[2 * i + 1] << 32);
