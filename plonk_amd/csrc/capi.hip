@@ -948,10 +948,12 @@ int msm_enqueue(plk_ctx* ctx, hipStream_t s, const uint64_t* scalars, size_t n, 
   const uint64_t total = (uint64_t)n * windows, nbuckets = 1ull << c;
   // lanes per bucket: about 32 entries each (measured flat between 20 and 45; their partial sums are added up by a
   // second kernel whose cost grows with the lane count)
-  uint32_t lanes = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, (total >> c) / 32));
+  // (at most half of MSM_BIG_BUCKET for the average bucket: the workgroup-per-bucket kernel is for the few crowded
+  // ones, and took 90 ms when half of all buckets of a 2^24-term sum sat just above its threshold)
+  uint32_t lanes = (uint32_t)std::min<uint64_t>(MSM_BIG_BUCKET / 2, std::max<uint64_t>(1, (total >> c) / 32));
   // a small sum does not fill the GPU (about 2 * 10^5 lanes at three waves per SIMD): its time is the longest chain of
   // additions, so the runs are split further while lanes are free
-  while (lanes < 64 && nbuckets * lanes * 2 <= 196608 && (total >> c) / (lanes * 2) >= 6) lanes *= 2;
+  while (lanes * 2 <= MSM_BIG_BUCKET / 2 && nbuckets * lanes * 2 <= 196608 && (total >> c) / (lanes * 2) >= 6) lanes *= 2;
   // that was the average bucket; every bucket gets one lane per `per_lane` entries of its own run (msm_lanes_kernel)
   const uint32_t per_lane = (uint32_t)std::max<uint64_t>(1, ((total >> c) + lanes - 1) / lanes);
   const uint64_t lane_bound = total / per_lane + nbuckets;          // sum of ceil(run / per_lane) over the buckets, at most
