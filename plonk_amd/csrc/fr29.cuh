@@ -90,8 +90,9 @@ __host__ __device__ __forceinline__ Fe fe_pack_f9(const F9& a) {
   return r;
 }
 
-// lazy F9 with value < 32 p -> canonical element in [0, p) as 8 x 32-bit words
-__host__ __device__ __forceinline__ Fe fe_reduce_f9(F9 a) {
+// lazy F9 with value < 32 p -> canonical element in [0, p) as 8 x 32-bit words, by conditional subtraction of
+// 16 p ... p: the plain form, kept as the check of fe_reduce_f9 (tools/test_reduce.hip)
+__host__ __device__ __forceinline__ Fe fe_reduce_f9_by_subtractions(F9 a) {
   f9_normalize(a);
   // 261-bit value as 9 x 32-bit words
   uint32_t w[9];
@@ -116,6 +117,28 @@ __host__ __device__ __forceinline__ Fe fe_reduce_f9(F9 a) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) r.l[j] = w[j];
   return r;
+}
+
+// lazy F9 with value v < 32 p -> canonical element in [0, p) as 8 x 32-bit words.
+// The quotient floor(v / p) < 32 is estimated from the top limb alone: qh = floor(float(l8) * C) with
+// C = (2^232 / p) (1 - 2^-20) rounded down to a float.  l8 <= v / 2^232 and the two float roundings raise the product
+// by less than a relative 2^-22, so qh <= v / p; l8 > v / 2^232 - 1 and the factors lower it by less than 1e-4 in all,
+// so qh >= floor(v / p) - 1.  Hence v - qh p lies in [0, 2 p): one signed carry chain over the limbs and one
+// conditional subtraction, instead of five conditional subtractions.
+__host__ __device__ __forceinline__ Fe fe_reduce_f9(F9 a) {
+  f9_normalize(a);
+  const uint32_t qh = (uint32_t)((float)a.l[8] * 0x1.1aa838p-23f);
+  int64_t acc = 0;
+  F9 r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    acc += (int64_t)a.l[i];
+    acc -= (int64_t)((uint64_t)qh * f9c::kp_limb29(1, i));
+    r.l[i] = i < 8 ? ((uint32_t)acc & M29) : (uint32_t)acc;
+    acc >>= 29;                                   // arithmetic: a borrow travels as -1
+  }
+  const Fe w = fe_pack_f9(r);                     // below 2 p < 2^256
+  return fe_reduce_once(w.l, 0);
 }
 
 // ---- arithmetic --------------------------------------------------------------------------
