@@ -46,6 +46,8 @@ def parse_args():
                     help="rows of the CPU-baseline run (log2); below --log-n the time is scaled by the row count")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="time the steps without the per-launch events (no roofline object)")
+    ap.add_argument("--no-lean-variant", action="store_true",
+                    help="skip the extra figure without the Int/Bool selector columns (a profiler run wants one launch shape per kernel)")
     return ap.parse_args()
 
 
@@ -348,7 +350,7 @@ def main():
     # one).  The reference transforms them and then multiplies their evaluations by F::zero()
     # (src/execution_trace.rs:396-397), so the three outputs cannot depend on them.
     lean = None
-    if world == 1 and {"Int", "Bool"} <= set(dc.selectors):
+    if world == 1 and not args.no_lean_variant and {"Int", "Bool"} <= set(dc.selectors):
         from plonk_amd.device import DeviceCircuit
         dc2 = DeviceCircuit(dc.n, dc.wires, {k: v for k, v in dc.selectors.items() if k not in ("Int", "Bool")}, dc.sigma, dc.beta, dc.gamma)
         out2 = (prover.empty(n + 1), prover.empty(N), prover.empty(N))
