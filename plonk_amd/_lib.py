@@ -29,6 +29,7 @@ MAX_BATCH = 24
 INPUT_FIELD = 0
 INPUT_U64 = 1
 NO_WIRE = (1 << 64) - 1
+NOALLOC_MAX_ROWS = 1 << 16
 
 u64p = C.POINTER(C.c_uint64)
 u64pp = C.POINTER(u64p)
@@ -77,6 +78,7 @@ SIGNATURES = {
     "plk_dev_mul": (C.c_int, [C.c_void_p, C.c_void_p, u64p, u64p, C.c_size_t, u64p]),
     "plk_dev_twiddle_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, u64p]),
     "plk_dev_grand_product": (C.c_int, [C.c_void_p, C.c_void_p, u64pp, u64pp, C.c_size_t, u64p, u64p, u64p]),
+    "plk_dev_grand_product_noalloc": (C.c_int, [C.c_void_p, C.c_void_p, u64pp, u64pp, C.c_size_t, u64p, u64p, u64p]),
     "plk_dev_grand_product_local": (C.c_int, [C.c_void_p, C.c_void_p, u64pp, u64pp, C.c_size_t, C.c_size_t, C.c_size_t, u64p, u64p, u64p]),
     "plk_dev_grand_product_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, u64p, C.c_size_t, C.c_size_t, u64p]),
     "plk_dev_gate_constraint_eval": (C.c_int, [C.c_void_p, C.c_void_p, u64pp, u64pp, C.c_size_t, u64p]),

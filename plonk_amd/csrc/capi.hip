@@ -33,6 +33,13 @@ namespace {
 
 constexpr size_t ELEM = 32;  // bytes per field element
 
+// The grand product's intermediate arrays: per-row terms and per-block products (grand_product.cuh).
+struct GpScratch {
+  uint64_t *num = nullptr, *den = nullptr;   // rows elements each
+  uint64_t *bn = nullptr, *bd = nullptr;     // one element per block of GP_BLOCK_ROWS rows
+};
+
+
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
@@ -47,6 +54,15 @@ struct NttPlan {
 };
 
 }  // namespace
+
+// Scratch of plk_dev_grand_product_noalloc, the entry point for callers that cannot allocate: a fixed array in the
+// code object instead of workspace slots.  Every GPU the library runs on holds its own copy, at its own address,
+// until the process ends.  In host code `scratch` is only a handle for hipGetSymbolAddress; the address the
+// kernels get is looked up once per device in plk_ctx_create and kept in the context.
+constexpr size_t NOALLOC_MAX_ROWS = size_t(1) << 16;
+constexpr size_t NOALLOC_MAX_BLOCKS = (NOALLOC_MAX_ROWS + GP_BLOCK_ROWS - 1) / GP_BLOCK_ROWS;
+constexpr size_t NOALLOC_SCRATCH_BYTES = (2 * NOALLOC_MAX_ROWS + 2 * NOALLOC_MAX_BLOCKS) * ELEM;   // 4 MiB + 4 KiB
+static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
 
 // Copies between ordinary (pageable) host memory and the device.  hipMemcpy stages such copies through one
 // thread; here COPY_WORKERS threads (the caller and a small pool that lives with the context) each copy chunks
@@ -123,6 +139,8 @@ struct plk_ctx {
   G1Jac* msm_sums = nullptr;                     // page-locked landing place of the sums (Jacobian, ABI form)
   size_t msm_sums_cap = 0;
   size_t gp_rows = 0;                            // rows of the grand-product range held in the workspace
+  GpScratch gp_sc;                               // where that range's terms and block products are
+  unsigned char* noalloc_ptr = nullptr;          // this device's address of the array `scratch`
   GpStatus* status_dev = nullptr;
   GpStatus* status_host = nullptr;  // pinned
   std::string last_error;
@@ -464,7 +482,7 @@ int status_reset(plk_ctx* ctx, hipStream_t s) {
 // the whole circuit and the inversion is done here; otherwise the range's numerator and denominator
 // products are written to totals[0..1] (device) and gp_apply_carries must run before gp_finish.
 int gp_local(plk_ctx* ctx, hipStream_t s, const uint64_t* const wires[4], const uint64_t* const sigma[4], size_t n, size_t first,
-             size_t rows, const uint64_t beta_[4], const uint64_t gamma_[4], uint64_t* totals) {
+             size_t rows, const uint64_t beta_[4], const uint64_t gamma_[4], uint64_t* totals, const GpScratch* fixed = nullptr) {
   if (!beta_ || !gamma_) return fail(ctx, PLK_ERR_ARG, "null pointer");
   if (rows == 0 || first > n || rows > n - first) return fail(ctx, PLK_ERR_ARG, "row range outside the circuit");
   const Fe beta = fe_from_limbs64(beta_), gamma = fe_from_limbs64(gamma_);
@@ -476,25 +494,32 @@ int gp_local(plk_ctx* ctx, hipStream_t s, const uint64_t* const wires[4], const 
     cols.sigma[k] = sigma[k];
   }
   const size_t nb = (rows + GP_BLOCK_ROWS - 1) / GP_BLOCK_ROWS;
-  void *num, *den, *bn, *bd;
-  int rc;
-  if ((rc = ws_get(ctx, "gp_num", rows * ELEM, &num))) return rc;
-  if ((rc = ws_get(ctx, "gp_den", rows * ELEM, &den))) return rc;
-  if ((rc = ws_get(ctx, "gp_bnum", nb * ELEM, &bn))) return rc;
-  if ((rc = ws_get(ctx, "gp_bden", nb * ELEM, &bd))) return rc;
+  GpScratch sc;
+  if (fixed) {
+    sc = *fixed;
+  } else {   // grow-only workspace slots of the context
+    void *num, *den, *bn, *bd;
+    int rc;
+    if ((rc = ws_get(ctx, "gp_num", rows * ELEM, &num))) return rc;
+    if ((rc = ws_get(ctx, "gp_den", rows * ELEM, &den))) return rc;
+    if ((rc = ws_get(ctx, "gp_bnum", nb * ELEM, &bn))) return rc;
+    if ((rc = ws_get(ctx, "gp_bden", nb * ELEM, &bd))) return rc;
+    sc.num = (uint64_t*)num; sc.den = (uint64_t*)den; sc.bn = (uint64_t*)bn; sc.bd = (uint64_t*)bd;
+  }
   const Fe beta_r2 = fe_mul(beta, fe_r2());
   {
     ProfScope ps(ctx, s, "gp_terms_kernel", 288.0 * (double)rows);   // 4 values + 4 indices + 4 gathers per row
     hipLaunchKernelGGL(gp_terms_kernel, dim3((unsigned)nb), dim3(GP_THREADS), 0, s, cols, (uint64_t)n, (uint64_t)first, (uint64_t)rows,
-                       beta, gamma, beta_r2, (uint64_t*)num, (uint64_t*)den, (uint64_t*)bn, (uint64_t*)bd, ctx->status_dev);
+                       beta, gamma, beta_r2, sc.num, sc.den, sc.bn, sc.bd, ctx->status_dev);
   }
   HIP_TRY(ctx, hipGetLastError());
   {
     ProfScope ps(ctx, s, "gp_block_scan_kernel", 0.0);
-    hipLaunchKernelGGL(gp_block_scan_kernel, dim3(1), dim3(GP_SCAN_THREADS), 0, s, (uint64_t*)bn, (uint64_t*)bd, (uint32_t)nb, totals);
+    hipLaunchKernelGGL(gp_block_scan_kernel, dim3(1), dim3(GP_SCAN_THREADS), 0, s, sc.bn, sc.bd, (uint32_t)nb, totals);
   }
   HIP_TRY(ctx, hipGetLastError());
   ctx->gp_rows = rows;
+  ctx->gp_sc = sc;
   return PLK_OK;
 }
 
@@ -504,7 +529,7 @@ int gp_apply_carries(plk_ctx* ctx, hipStream_t s, const uint64_t* totals_all, si
   const size_t nb = (ctx->gp_rows + GP_BLOCK_ROWS - 1) / GP_BLOCK_ROWS;
   ProfScope ps(ctx, s, "gp_carry_kernel", 0.0);
   hipLaunchKernelGGL(gp_carry_kernel, dim3(1), dim3(GP_THREADS), 0, s, totals_all, (uint32_t)ranges, (uint32_t)mine,
-                     (uint64_t*)ctx->ws["gp_bnum"].p, (uint64_t*)ctx->ws["gp_bden"].p, (uint32_t)nb);
+                     ctx->gp_sc.bn, ctx->gp_sc.bd, (uint32_t)nb);
   HIP_TRY(ctx, hipGetLastError());
   return PLK_OK;
 }
@@ -514,16 +539,16 @@ int gp_finish(plk_ctx* ctx, hipStream_t s, uint64_t* z_after, uint64_t* z0) {
   if (!z_after) return fail(ctx, PLK_ERR_ARG, "null pointer");
   const size_t rows = ctx->gp_rows;
   const size_t nb = (rows + GP_BLOCK_ROWS - 1) / GP_BLOCK_ROWS;
+  const GpScratch& sc = ctx->gp_sc;
   ProfScope ps(ctx, s, "gp_finish_kernel", 32.0 * (double)(rows + 1));   // the z column
-  hipLaunchKernelGGL(gp_finish_kernel, dim3((unsigned)nb), dim3(GP_THREADS), 0, s, (const uint64_t*)ctx->ws["gp_num"].p,
-                     (const uint64_t*)ctx->ws["gp_den"].p, (uint64_t)rows, (const uint64_t*)ctx->ws["gp_bnum"].p,
-                     (const uint64_t*)ctx->ws["gp_bden"].p, z_after, z0);
+  hipLaunchKernelGGL(gp_finish_kernel, dim3((unsigned)nb), dim3(GP_THREADS), 0, s, (const uint64_t*)sc.num, (const uint64_t*)sc.den,
+                     (uint64_t)rows, (const uint64_t*)sc.bn, (const uint64_t*)sc.bd, z_after, z0);
   HIP_TRY(ctx, hipGetLastError());
   return PLK_OK;
 }
 
 int launch_grand_product(plk_ctx* ctx, hipStream_t s, const uint64_t* const wires[4], const uint64_t* const sigma[4],
-                         size_t n, const uint64_t beta_[4], const uint64_t gamma_[4], uint64_t* z_out) {
+                         size_t n, const uint64_t beta_[4], const uint64_t gamma_[4], uint64_t* z_out, const GpScratch* fixed = nullptr) {
   if (!z_out || !beta_ || !gamma_) return fail(ctx, PLK_ERR_ARG, "null pointer");
   if (n == 0) {  // z = [1]
     const Fe one = fe_one();
@@ -532,7 +557,7 @@ int launch_grand_product(plk_ctx* ctx, hipStream_t s, const uint64_t* const wire
     return PLK_OK;
   }
   int rc;
-  if ((rc = gp_local(ctx, s, wires, sigma, n, 0, n, beta_, gamma_, nullptr))) return rc;
+  if ((rc = gp_local(ctx, s, wires, sigma, n, 0, n, beta_, gamma_, nullptr, fixed))) return rc;
   return gp_finish(ctx, s, z_out + 4, z_out);
 }
 
@@ -1264,6 +1289,15 @@ int plk_ctx_create(int device, plk_ctx** out) {
   CTX_TRY(hipMalloc((void**)&ctx->status_dev, sizeof(GpStatus)));
   CTX_TRY(hipHostMalloc((void**)&ctx->status_host, sizeof(GpStatus)));
   CTX_TRY(hipMemset(ctx->status_dev, 0xff, sizeof(GpStatus)));
+  // this device's copy of the fixed scratch array (the device is current: hipSetDevice above); loading the kernels of
+  // the entry point that uses it now keeps its first call free of the runtime's own lazy set-up
+  CTX_TRY(hipGetSymbolAddress((void**)&ctx->noalloc_ptr, HIP_SYMBOL(scratch)));
+  {
+    hipFuncAttributes fa;
+    CTX_TRY(hipFuncGetAttributes(&fa, (const void*)gp_terms_kernel));
+    CTX_TRY(hipFuncGetAttributes(&fa, (const void*)gp_block_scan_kernel));
+    CTX_TRY(hipFuncGetAttributes(&fa, (const void*)gp_finish_kernel));
+  }
   CTX_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES));
   CTX_TRY(hipFuncSetAttribute((const void*)ntt_final_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES));
 #undef CTX_TRY
@@ -1401,6 +1435,26 @@ int plk_dev_grand_product(plk_ctx* ctx, void* stream, const uint64_t* const wire
   if (rc) return rc;
   if (!wires || !sigma) return fail(ctx, PLK_ERR_ARG, "null pointer table");
   return launch_grand_product(ctx, (hipStream_t)stream, wires, sigma, n, beta, gamma, z_out);
+}
+
+int plk_dev_grand_product_noalloc(plk_ctx* ctx, void* stream, const uint64_t* const wires[4], const uint64_t* const sigma[4], size_t n,
+                                  const uint64_t beta[4], const uint64_t gamma[4], uint64_t* z_out) {
+  int rc = use_device(ctx);
+  if (rc) return rc;
+  if (!wires || !sigma) return fail(ctx, PLK_ERR_ARG, "null pointer table");
+  if (n > NOALLOC_MAX_ROWS)
+    return fail(ctx, PLK_ERR_ARG, "plk_dev_grand_product_noalloc takes at most " + std::to_string(NOALLOC_MAX_ROWS) + " rows, got " +
+                                      std::to_string(n) + ": use plk_dev_grand_product");
+  if (ctx->profiling) return fail(ctx, PLK_ERR_ARG, "plk_dev_grand_product_noalloc is not available between plk_profile_begin/end (events are allocated there)");
+  // the fixed array, cut as [num | den | block numerators | block denominators]; every word a kernel reads here was
+  // written by an earlier kernel of this call, so nothing has to be cleared between calls
+  GpScratch sc;
+  unsigned char* base = ctx->noalloc_ptr;
+  sc.num = (uint64_t*)base;
+  sc.den = (uint64_t*)(base + NOALLOC_MAX_ROWS * ELEM);
+  sc.bn = (uint64_t*)(base + 2 * NOALLOC_MAX_ROWS * ELEM);
+  sc.bd = (uint64_t*)(base + (2 * NOALLOC_MAX_ROWS + NOALLOC_MAX_BLOCKS) * ELEM);
+  return launch_grand_product(ctx, (hipStream_t)stream, wires, sigma, n, beta, gamma, z_out, &sc);
 }
 
 int plk_dev_grand_product_local(plk_ctx* ctx, void* stream, const uint64_t* const wires[4], const uint64_t* const sigma[4], size_t n,

@@ -185,6 +185,12 @@ class DeviceProver:
                                                       dc.beta.ctypes.data_as(_lib.u64p), dc.gamma.ctypes.data_as(_lib.u64p), _ptr(z)))
         return z
 
+    def grand_product_noalloc(self, dc: DeviceCircuit, out: torch.Tensor) -> torch.Tensor:
+        """The grand product through the entry point that allocates nothing; `out` is the caller's `(n + 1, 4)` tensor."""
+        self.ctx.check(self.lib.plk_dev_grand_product_noalloc(self.ctx.handle, self._stream(), _table(dc.wires), _table(dc.sigma), dc.n,
+                                                              dc.beta.ctypes.data_as(_lib.u64p), dc.gamma.ctypes.data_as(_lib.u64p), _ptr(out)))
+        return out
+
     def gate_constraint_eval(self, wire_evals, sel_evals: Dict[str, torch.Tensor], N: int, out=None) -> torch.Tensor:
         out = self.empty(N) if out is None else out
         sels = [sel_evals.get(k) for k in AST_KINDS]
