@@ -28,6 +28,12 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak
 NTT_ROOFLINE_GELEM = HBM_PEAK_GBS / 64.0   # 64 algorithmic bytes per element per transform
+# The roof that binds the transforms in practice: 256-bit modular products per second.  Measured on MI355X with
+# nothing else in the kernel (tools/ubench_shoup.hip, the library's mont29_x2 at the transform kernels' occupancy of
+# 4 waves per SIMD; profiles/r02_ubench_products.txt): 150 G products/s.  The bound from multiply-add issue alone
+# (153 v_mad_u64_u32 per product at the 31.4 T lane-ops/s of tools/ubench_valu.hip) would be 205 G products/s.
+VALU_PEAK_GPRODUCTS = 150.0
+VALU_MAD_ISSUE_BOUND_GPRODUCTS = 205.0
 
 
 def parse_args():
@@ -387,6 +393,20 @@ def main():
                                 "256-bit modular products keep the vector ALUs issuing back to back (see "
                                 "valu_cycles_per_inst_per_simd against the ~4.2 cycles this instruction mix costs): the kernel "
                                 "is bound by integer multiply-add issue"}
+        roofline_valu = None
+        if dom and dom.get("products", 0) > 0:
+            gp = dom["products"] / dom["launches"] / (per_launch_ms * 1e-3) / 1e9
+            all_products = sum(r.get("products", 0.0) for r in prof) / args.steps
+            roofline_valu = {"bound": "valu", "kernel": dom["label"], "achieved": round(gp, 1), "peak": VALU_PEAK_GPRODUCTS,
+                             "unit": "G products/s", "frac": round(gp / VALU_PEAK_GPRODUCTS, 4),
+                             "products_per_launch": dom["products"] / dom["launches"],
+                             "mad_issue_bound": VALU_MAD_ISSUE_BOUND_GPRODUCTS,
+                             "step_products": all_products,
+                             "step_products_per_s_G": round(all_products / (ms_per_step * 1e-3) / 1e9, 1),
+                             "note": "256-bit modular products of the launch (counted from its shape: in-tile butterflies, "
+                                     "inter-pass twiddle, coset prescale, u64 conversion) over its measured duration; peak = the "
+                                     "same product routine alone in a kernel at the same occupancy (tools/ubench_shoup.hip). "
+                                     "This, not HBM, is the roof the transform kernels sit under"}
         # whole-transform throughput of the extension (all launches of the N-point forward transform)
         lde = [r for r in prof if f"/ntt{args.log_n + args.blowup.bit_length() - 1}" in r["label"] or "/lde" in r["label"]]
         ntt = None
@@ -409,9 +429,10 @@ def main():
             "proofs_per_s": round(world / (ms_per_step * 1e-3), 3),
             "step_alg_bytes": alg_bytes_step,
             "step_frac_of_hbm_roofline": round(alg_bytes_step / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if alg_bytes_step else None,
-            "roofline": roofline, "ntt": ntt, "without_int_bool_selectors": lean,
+            "roofline": roofline, "roofline_valu": roofline_valu, "ntt": ntt, "without_int_bool_selectors": lean,
             "kernels": [{"label": r["label"], "launches": r["launches"], "ms_per_step": round(r["total_ms"] / args.steps, 4),
-                         "alg_GBps": round(r["alg_bytes"] / max(r["total_ms"], 1e-9) / 1e6, 1)} for r in prof],
+                         "alg_GBps": round(r["alg_bytes"] / max(r["total_ms"], 1e-9) / 1e6, 1),
+                         "Gproducts_per_s": round(r.get("products", 0.0) / max(r["total_ms"], 1e-9) / 1e6, 1)} for r in prof],
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.log_n, args.blowup, min(args.cpu_sample_log_n, args.log_n))

@@ -19,7 +19,18 @@
  *    pointer.  Device entry points (`plk_dev_*`) take device memory of the context's GPU and
  *    enqueue on the given hipStream_t (passed as void*); data-dependent failures (zero
  *    denominator, sigma out of range) are reported by plk_dev_status().
- *  - One context per GPU; a context must not be used from two threads at once.
+ *  - One context per GPU; a context must not be used from two threads at once.  The context's workspace, status
+ *    word and side stream are shared by all its calls, so the library orders them: a device call given another
+ *    stream than the context's previous call first makes that stream wait (hipStreamWaitEvent) for the work the
+ *    previous call enqueued.  Calls on one context therefore never overlap on the GPU; use one context per
+ *    stream for overlap (except plk_dev_grand_product_noalloc, whose fixed array is shared per GPU).
+ *  - Preconditions on data, not checked: every element of every column is reduced (< p), as ark-ff guarantees
+ *    for `Fp256`; an unreduced limb pattern gives a wrong element, not an error.  beta, gamma, shift, alpha and
+ *    default_val ARE checked (PLK_ERR_ARG).
+ *  - sigma range: the reference indexes each wire column with its own sigma column
+ *    (src/permutation_polynomial.rs:235-238), so with columns of unequal length an index is legal up to that
+ *    column's length; here all four columns have the n rows of `input1` and any index >= n is
+ *    PLK_ERR_SIGMA_RANGE.
  */
 #ifndef PLONK_HIP_H
 #define PLONK_HIP_H

@@ -195,7 +195,8 @@ class Context:
         p = C.c_void_p()
         self.check(self.lib.plk_host_alloc(self.handle, nbytes, C.byref(p)))
         buf = (C.c_uint8 * max(nbytes, 1)).from_address(p.value)
-        weakref.finalize(buf, self.lib.plk_host_free, self.handle, p)
+        # plk_host_free ignores its context argument, so the buffer may outlive this context
+        weakref.finalize(buf, self.lib.plk_host_free, None, p)
         return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
     def check(self, rc: int):

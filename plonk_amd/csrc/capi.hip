@@ -129,6 +129,12 @@ struct plk_ctx {
   hipStream_t stream = nullptr;  // used by the host entry points
   hipStream_t aux = nullptr;     // side stream of plk_round23: the grand-product chain runs beside the transforms
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // The workspace, the status word and the side stream are shared by every call on the context, so calls are
+  // ordered one after another whatever stream they are given: when a device call arrives on another stream
+  // than the previous one, the new stream first waits for an event recorded at the end of the old one.
+  hipStream_t last_stream = nullptr;
+  bool have_last_stream = false;
+  hipEvent_t ev_order = nullptr;
   std::map<std::pair<int, int>, NttPlan> plans;  // (log_n, inverse)
   std::map<std::string, DevBuf> ws;              // grow-only workspace slots
   struct PowTable { DevBuf lo, hi; size_t hi_count = 0; };
@@ -147,7 +153,7 @@ struct plk_ctx {
   long long last_row = -1;
   // optional per-launch timing (plk_profile_*): one event pair per kernel launch
   bool profiling = false;
-  struct ProfRec { std::string label; hipEvent_t e0, e1; double alg_bytes; };
+  struct ProfRec { std::string label; hipEvent_t e0, e1; double alg_bytes; double products; };
   std::vector<ProfRec> prof;
   std::vector<hipEvent_t> event_pool;
   std::string prof_report;
@@ -163,14 +169,19 @@ int fail(plk_ctx* ctx, int code, const std::string& msg) {
 // Brackets one kernel launch with HIP events on the launch stream when profiling is on.
 struct ProfScope {
   plk_ctx* ctx; hipStream_t s; size_t idx = (size_t)-1;
-  ProfScope(plk_ctx* c, hipStream_t st, const std::string& label, double alg_bytes) : ctx(c), s(st) {
+  // alg_bytes: compulsory bytes of the launch; products: 256-bit modular products it performs (0 = not counted)
+  ProfScope(plk_ctx* c, hipStream_t st, const std::string& label, double alg_bytes, double products = 0.0) : ctx(c), s(st) {
     if (!ctx->profiling) return;
-    hipEvent_t ev[2];
+    hipEvent_t ev[2] = {nullptr, nullptr};
     for (auto& e : ev) {
       if (!ctx->event_pool.empty()) { e = ctx->event_pool.back(); ctx->event_pool.pop_back(); }
-      else if (hipEventCreate(&e) != hipSuccess) return;
+      else if (hipEventCreate(&e) != hipSuccess) {
+        (void)hipGetLastError();
+        if (ev[0]) ctx->event_pool.push_back(ev[0]);   // the first event goes back to the pool
+        return;
+      }
     }
-    ctx->prof.push_back({label, ev[0], ev[1], alg_bytes});
+    ctx->prof.push_back({label, ev[0], ev[1], alg_bytes, products});
     idx = ctx->prof.size() - 1;
     (void)hipEventRecord(ev[0], s);
   }
@@ -244,11 +255,21 @@ int alloc_table(plk_ctx* ctx, DevBuf& buf, uint64_t count, const Fe& base, int s
   return PLK_OK;
 }
 
+void free_plan_tables(NttPlan& p) {
+  for (DevBuf* b : {&p.master, &p.hi, &p.hi_scaled, &p.lo, &p.scale, &p.from_u64, &p.full[0], &p.full[1], &p.prescale4})
+    if (b->p) { (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
+}
+
 int get_plan(plk_ctx* ctx, int log_n, bool inverse, hipStream_t s, NttPlan** out) {
   auto key = std::make_pair(log_n, inverse ? 1 : 0);
   auto it = ctx->plans.find(key);
   if (it != ctx->plans.end()) { *out = &it->second; return PLK_OK; }
   NttPlan plan;
+  // a failure midway (a full table can be 1.5 GiB) must not leave the tables built so far behind
+  struct PlanGuard {
+    NttPlan* p;
+    ~PlanGuard() { if (p) free_plan_tables(*p); }
+  } guard{&plan};
   plan.log_n = log_n;
   plan.npass = log_n <= NTT_TILE_LOG ? 1 : (log_n <= 16 ? 2 : 3);
   const int base = log_n / plan.npass, rem = log_n % plan.npass;
@@ -315,6 +336,7 @@ int get_plan(plk_ctx* ctx, int log_n, bool inverse, hipStream_t s, NttPlan** out
   // tables may be used from another stream than the one that built them
   HIP_TRY(ctx, hipStreamSynchronize(s));
   auto ins = ctx->plans.emplace(key, plan);
+  guard.p = nullptr;
   *out = &ins.first->second;
   return PLK_OK;
 }
@@ -378,6 +400,21 @@ int launch_ntt(plk_ctx* ctx, hipStream_t s, const uint64_t* const* in, const uin
   const std::string tag = (cosets ? "/lde" + std::to_string(log_n) + "to" + std::to_string(log_n + 2)
                                   : std::string(inverse ? "/intt" : "/ntt") + std::to_string(log_n) + (n_in < N ? "lde" : "")) +
                           (std::string(tmp_slot) == "ntt_tmp" ? "" : "/side");
+  // field products per element inside a tile transform of radix 2^lr (ntt.cuh, tile_transform): the first two
+  // stages cost one product per four elements (none when only a quarter of the rows is non-zero), every later pair
+  // of stages one per element, a single stage left over one per two elements
+  auto tile_products = [&](int lr, bool quarter) {
+    if (lr < 2) return 0.0;
+    return (quarter ? 0.0 : 0.25) + (double)((lr - 2) / 2) + 0.5 * (double)((lr - 2) % 2);
+  };
+  const bool quarter_in = (n_in << 2) <= N;
+  const double elems = (double)N * (double)slots;
+  // F::from(u64) on load is one more product per element of such a column (first pass only)
+  double u64_products = 0.0;
+  if (kinds) {
+    if (stride_in) u64_products = kinds[0] == NTT_IN_U64 ? (double)n_in * (double)batch : 0.0;
+    else for (size_t b = 0; b < batch; ++b) if (kinds[b] == NTT_IN_U64) u64_products += (double)n_in;
+  }
   auto from_user = [&](NttBatch& b) { for (int i = 0; i < NTT_MAX_BATCH; ++i) { b.in[i] = user.in[i]; b.kind[i] = user.kind[i]; } b.stride_in = user.stride_in; };
   auto to_user = [&](NttBatch& b) { for (int i = 0; i < NTT_MAX_BATCH; ++i) b.out[i] = user.out[i]; b.stride_out = user.stride_out; };
   auto from_tmp = [&](NttBatch& b) { b.in[0] = tmp; b.stride_in = (uint64_t)N * 4; b.kind[0] = NTT_IN_FIELD; };
@@ -407,7 +444,9 @@ int launch_ntt(plk_ctx* ctx, hipStream_t s, const uint64_t* const* in, const uin
     const uint64_t tiles = 1ull << (log_n - lr - a.log_c);
     if (tiles * slots > 0x7fffffffull) return fail(ctx, PLK_ERR_ARG, "transform batch too large for one launch");
     a.slots = (uint32_t)slots;
-    ProfScope ps(ctx, s, "ntt_pass_kernel" + tag + "/p" + std::to_string(p), alg_share);
+    // + the inter-pass twiddle (two products through the two-level table), + the coset prescale in the first pass
+    const double per_elem = tile_products(lr, p == 0 && quarter_in) + (plan->tab.tw_full[p] ? 1.0 : 2.0) + ((p == 0 && cosets) ? 1.0 : 0.0);
+    ProfScope ps(ctx, s, "ntt_pass_kernel" + tag + "/p" + std::to_string(p), alg_share, per_elem * elems + (p == 0 ? u64_products : 0.0));
     hipLaunchKernelGGL(ntt_pass_kernel, dim3((unsigned)(tiles * slots)), dim3(NTT_THREADS), lds_bytes, s, a);
     HIP_TRY(ctx, hipGetLastError());
   }
@@ -427,7 +466,8 @@ int launch_ntt(plk_ctx* ctx, hipStream_t s, const uint64_t* const* in, const uin
     if (P == 1) from_user(a.batch); else from_tmp(a.batch);
     to_user(a.batch);
     const unsigned tiles = 1u << (log_n - a.log_r - a.log_c);
-    ProfScope ps(ctx, s, "ntt_final_kernel" + tag, alg_share);
+    const double per_elem = tile_products(a.log_r, P == 1 && quarter_in) + (plan->tab.scale ? 1.0 : 0.0) + ((P == 1 && cosets) ? 1.0 : 0.0);
+    ProfScope ps(ctx, s, "ntt_final_kernel" + tag, alg_share, per_elem * elems + (P == 1 ? u64_products : 0.0));
     hipLaunchKernelGGL(ntt_final_kernel, dim3(tiles, (unsigned)slots), dim3(NTT_THREADS), lds_bytes, s, a);
     HIP_TRY(ctx, hipGetLastError());
   }
@@ -572,7 +612,7 @@ int launch_gate_eval(plk_ctx* ctx, hipStream_t s, const uint64_t* const w[4], co
   int ncols = 5;
   for (int k = 0; k < 9; ++k) ncols += cols.s[k] != nullptr;
   {
-  ProfScope ps(ctx, s, "gate_constraint_kernel", 32.0 * ncols * (double)N);
+  ProfScope ps(ctx, s, "gate_constraint_kernel", 32.0 * ncols * (double)N, 12.0 * (double)N);
   hipLaunchKernelGGL(gate_constraint_kernel, dim3(blocks), dim3(EW_THREADS), 0, s, cols, (uint64_t)N, out);
   }
   HIP_TRY(ctx, hipGetLastError());
@@ -598,7 +638,7 @@ int launch_perm_eval(plk_ctx* ctx, hipStream_t s, const uint64_t* z, const uint6
   const Fe beta_r2 = fe_mul(beta, fe_r2());
   const unsigned blocks = (unsigned)((N + EW_THREADS - 1) / EW_THREADS);
   {
-  ProfScope ps(ctx, s, "perm_constraint_kernel", 320.0 * (double)N);
+  ProfScope ps(ctx, s, "perm_constraint_kernel", 320.0 * (double)N, 18.0 * (double)N);
   hipLaunchKernelGGL(perm_constraint_kernel, dim3(blocks), dim3(EW_THREADS), 0, s, cols, (uint64_t)N, (uint64_t)index0,
                      (uint64_t)z_len, beta, gamma, beta_r2, (uint64_t)z_shift, out);
   }
@@ -665,7 +705,7 @@ int launch_round23(plk_ctx* ctx, hipStream_t s, const uint64_t* const wires[4], 
       int ncols = 5;
       for (int k = 0; k < 4; ++k) { g.w0[k] = wires[k]; g.w[k] = col_cos(k); }
       for (int k = 0; k < 9; ++k) { const bool on = sel && sel[k]; g.s0[k] = on ? sel[k] : nullptr; g.s[k] = on ? col_cos(4 + k) : nullptr; ncols += on; }
-      ProfScope ps(ctx, s, "gate_constraint_coset_kernel", 32.0 * ncols * (double)N);
+      ProfScope ps(ctx, s, "gate_constraint_coset_kernel", 32.0 * ncols * (double)N, 12.0 * (double)N);
       hipLaunchKernelGGL(gate_constraint_coset_kernel, dim3((unsigned)((N + EW_THREADS - 1) / EW_THREADS)), dim3(EW_THREADS), 0, s, g,
                          (uint64_t)n, gate_out);
       HIP_TRY(ctx, hipGetLastError());
@@ -676,7 +716,7 @@ int launch_round23(plk_ctx* ctx, hipStream_t s, const uint64_t* const wires[4], 
       PermColsCoset pc{};
       pc.z0 = z; pc.z = col_cos(17);
       for (int k = 0; k < 4; ++k) { pc.sig0[k] = sigma[k]; pc.sig[k] = col_cos(13 + k); pc.w0[k] = wires[k]; pc.w[k] = col_cos(k); }
-      ProfScope ps(ctx, s, "perm_constraint_coset_kernel", 320.0 * (double)N);
+      ProfScope ps(ctx, s, "perm_constraint_coset_kernel", 320.0 * (double)N, 18.0 * (double)N);
       hipLaunchKernelGGL(perm_constraint_coset_kernel, dim3((unsigned)((N + EW_THREADS - 1) / EW_THREADS)), dim3(EW_THREADS), 0, s, pc,
                          (uint64_t)n, fb, fg, fe_mul(fb, fe_r2()), (uint64_t)(z_shift % N), perm_out);
       HIP_TRY(ctx, hipGetLastError());
@@ -1253,6 +1293,26 @@ int use_device(plk_ctx* ctx) {
   return PLK_OK;
 }
 
+// Prologue of every entry point that enqueues on a stream: use_device, then order the stream behind the
+// context's previous call if that went to another stream.
+int use_stream(plk_ctx* ctx, hipStream_t s) {
+  int rc = use_device(ctx);
+  if (rc) return rc;
+  if (ctx->have_last_stream && ctx->last_stream != s) {
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_order, ctx->last_stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_order, 0));
+  }
+  ctx->last_stream = s;
+  ctx->have_last_stream = true;
+  return PLK_OK;
+}
+
+// the host entry points enqueue on the context's own stream
+int use_host_stream(plk_ctx* ctx) {
+  if (!ctx) return PLK_ERR_ARG;
+  return use_stream(ctx, ctx->stream);
+}
+
 }  // namespace
 
 // ============================================================================ extern "C"
@@ -1286,6 +1346,7 @@ int plk_ctx_create(int device, plk_ctx** out) {
   CTX_TRY(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
   CTX_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
   CTX_TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+  CTX_TRY(hipEventCreateWithFlags(&ctx->ev_order, hipEventDisableTiming));
   CTX_TRY(hipMalloc((void**)&ctx->status_dev, sizeof(GpStatus)));
   CTX_TRY(hipHostMalloc((void**)&ctx->status_host, sizeof(GpStatus)));
   CTX_TRY(hipMemset(ctx->status_dev, 0xff, sizeof(GpStatus)));
@@ -1310,10 +1371,7 @@ void plk_ctx_destroy(plk_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   (void)hipDeviceSynchronize();
-  for (auto& kv : ctx->plans) {
-    NttPlan& p = kv.second;
-    for (DevBuf* b : {&p.master, &p.hi, &p.hi_scaled, &p.lo, &p.scale, &p.from_u64, &p.full[0], &p.full[1], &p.prescale4}) if (b->p) (void)hipFree(b->p);
-  }
+  for (auto& kv : ctx->plans) free_plan_tables(kv.second);
   for (auto& kv : ctx->ws) if (kv.second.p) (void)hipFree(kv.second.p);
   msm_free_table(ctx);
   if (ctx->msm_sums) (void)hipHostFree(ctx->msm_sums);
@@ -1329,6 +1387,7 @@ void plk_ctx_destroy(plk_ctx* ctx) {
   if (ctx->status_host) (void)hipHostFree(ctx->status_host);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+  if (ctx->ev_order) (void)hipEventDestroy(ctx->ev_order);
   if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -1344,9 +1403,10 @@ int plk_host_alloc(plk_ctx* ctx, size_t bytes, void** out) {
 }
 
 void plk_host_free(plk_ctx* ctx, void* p) {
-  if (!ctx || !p) return;
-  (void)hipSetDevice(ctx->device);
-  (void)hipHostFree(p);
+  // the context is not touched: page-locked memory is freed without a current device, and a buffer may outlive
+  // the context it was allocated through (a finalizer that runs after plk_ctx_destroy)
+  (void)ctx;
+  if (p) (void)hipHostFree(p);
 }
 
 const char* plk_strerror(int code) {
@@ -1389,7 +1449,7 @@ const char* plk_profile_end(plk_ctx* ctx) {
   ctx->profiling = false;
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
-  struct Agg { size_t launches = 0; double ms = 0, bytes = 0; };
+  struct Agg { size_t launches = 0; double ms = 0, bytes = 0, products = 0; };
   std::vector<std::string> order;
   std::map<std::string, Agg> agg;
   for (auto& r : ctx->prof) {
@@ -1397,7 +1457,7 @@ const char* plk_profile_end(plk_ctx* ctx) {
     if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) ms = 0;
     if (!agg.count(r.label)) order.push_back(r.label);
     Agg& a = agg[r.label];
-    a.launches += 1; a.ms += ms; a.bytes += r.alg_bytes;
+    a.launches += 1; a.ms += ms; a.bytes += r.alg_bytes; a.products += r.products;
     ctx->event_pool.push_back(r.e0); ctx->event_pool.push_back(r.e1);
   }
   ctx->prof.clear();
@@ -1405,8 +1465,8 @@ const char* plk_profile_end(plk_ctx* ctx) {
   char buf[512];
   for (size_t i = 0; i < order.size(); ++i) {
     const Agg& a = agg[order[i]];
-    snprintf(buf, sizeof buf, "%s{\"label\": \"%s\", \"launches\": %zu, \"total_ms\": %.6f, \"alg_bytes\": %.1f}",
-             i ? ", " : "", order[i].c_str(), a.launches, a.ms, a.bytes);
+    snprintf(buf, sizeof buf, "%s{\"label\": \"%s\", \"launches\": %zu, \"total_ms\": %.6f, \"alg_bytes\": %.1f, \"products\": %.1f}",
+             i ? ", " : "", order[i].c_str(), a.launches, a.ms, a.bytes, a.products);
     out += buf;
   }
   out += "]";
@@ -1418,7 +1478,7 @@ const char* plk_profile_end(plk_ctx* ctx) {
 
 int plk_dev_ntt_batch(plk_ctx* ctx, void* stream, const uint64_t* const* in, const uint32_t* kinds, size_t batch,
                       size_t n_in, size_t N, int inverse, uint64_t* const* out) {
-  int rc = use_device(ctx);
+  int rc = use_stream(ctx, (hipStream_t)stream);
   if (rc) return rc;
   if (!in || !out) return fail(ctx, PLK_ERR_ARG, "null pointer table");
   for (size_t done = 0; done < batch; done += NTT_MAX_BATCH) {
@@ -1431,7 +1491,7 @@ int plk_dev_ntt_batch(plk_ctx* ctx, void* stream, const uint64_t* const* in, con
 
 int plk_dev_grand_product(plk_ctx* ctx, void* stream, const uint64_t* const wires[4], const uint64_t* const sigma[4], size_t n,
                           const uint64_t beta[4], const uint64_t gamma[4], uint64_t* z_out) {
-  int rc = use_device(ctx);
+  int rc = use_stream(ctx, (hipStream_t)stream);
   if (rc) return rc;
   if (!wires || !sigma) return fail(ctx, PLK_ERR_ARG, "null pointer table");
   return launch_grand_product(ctx, (hipStream_t)stream, wires, sigma, n, beta, gamma, z_out);
@@ -1439,7 +1499,7 @@ int plk_dev_grand_product(plk_ctx* ctx, void* stream, const uint64_t* const wire
 
 int plk_dev_grand_product_noalloc(plk_ctx* ctx, void* stream, const uint64_t* const wires[4], const uint64_t* const sigma[4], size_t n,
                                   const uint64_t beta[4], const uint64_t gamma[4], uint64_t* z_out) {
-  int rc = use_device(ctx);
+  int rc = use_stream(ctx, (hipStream_t)stream);
   if (rc) return rc;
   if (!wires || !sigma) return fail(ctx, PLK_ERR_ARG, "null pointer table");
   if (n > NOALLOC_MAX_ROWS)
@@ -1459,7 +1519,7 @@ int plk_dev_grand_product_noalloc(plk_ctx* ctx, void* stream, const uint64_t* co
 
 int plk_dev_grand_product_local(plk_ctx* ctx, void* stream, const uint64_t* const wires[4], const uint64_t* const sigma[4], size_t n,
                                 size_t first, size_t rows, const uint64_t beta[4], const uint64_t gamma[4], uint64_t* totals_out) {
-  int rc = use_device(ctx);
+  int rc = use_stream(ctx, (hipStream_t)stream);
   if (rc) return rc;
   if (!wires || !sigma || !totals_out) return fail(ctx, PLK_ERR_ARG, "null pointer");
   return gp_local(ctx, (hipStream_t)stream, wires, sigma, n, first, rows, beta, gamma, totals_out);
@@ -1467,7 +1527,7 @@ int plk_dev_grand_product_local(plk_ctx* ctx, void* stream, const uint64_t* cons
 
 int plk_dev_grand_product_finish(plk_ctx* ctx, void* stream, size_t rows, const uint64_t* totals_all, size_t ranges, size_t mine,
                                  uint64_t* z_after_out) {
-  int rc = use_device(ctx);
+  int rc = use_stream(ctx, (hipStream_t)stream);
   if (rc) return rc;
   if (rows == 0 || rows != ctx->gp_rows) return fail(ctx, PLK_ERR_ARG, "rows differ from the preceding plk_dev_grand_product_local");
   if ((rc = gp_apply_carries(ctx, (hipStream_t)stream, totals_all, ranges, mine))) return rc;
@@ -1475,7 +1535,7 @@ int plk_dev_grand_product_finish(plk_ctx* ctx, void* stream, size_t rows, const 
 }
 
 int plk_dev_msm_set_bases(plk_ctx* ctx, const uint64_t* bases_dev, size_t n) {
-  int rc = use_device(ctx);
+  int rc = use_host_stream(ctx);
   if (rc) return rc;
   if (!bases_dev && n) return fail(ctx, PLK_ERR_ARG, "null pointer");
   HIP_TRY(ctx, hipDeviceSynchronize());          // the caller's table may have been written on any stream
@@ -1483,7 +1543,7 @@ int plk_dev_msm_set_bases(plk_ctx* ctx, const uint64_t* bases_dev, size_t n) {
 }
 
 int plk_dev_msm_g1(plk_ctx* ctx, void* stream, const uint64_t* scalars_dev, size_t n, uint64_t out_xy[12]) {
-  int rc = use_device(ctx);
+  int rc = use_stream(ctx, (hipStream_t)stream);
   if (rc) return rc;
   if (!scalars_dev && n) return fail(ctx, PLK_ERR_ARG, "null pointer");
   const uint64_t* one[1] = {scalars_dev};
@@ -1491,13 +1551,13 @@ int plk_dev_msm_g1(plk_ctx* ctx, void* stream, const uint64_t* scalars_dev, size
 }
 
 int plk_dev_msm_g1_batch(plk_ctx* ctx, void* stream, const uint64_t* const scalars_dev[], size_t count, size_t n, uint64_t* out_xy) {
-  int rc = use_device(ctx);
+  int rc = use_stream(ctx, (hipStream_t)stream);
   if (rc) return rc;
   return launch_msm(ctx, (hipStream_t)stream, scalars_dev, count, n, out_xy);
 }
 
 int plk_dev_g1_multiples(plk_ctx* ctx, void* stream, const uint64_t base_xy[12], uint64_t first, size_t count, uint64_t* out_dev) {
-  int rc = use_device(ctx);
+  int rc = use_stream(ctx, (hipStream_t)stream);
   if (rc) return rc;
   if (!base_xy || (!out_dev && count)) return fail(ctx, PLK_ERR_ARG, "null pointer");
   if (count == 0) return PLK_OK;
@@ -1513,7 +1573,7 @@ int plk_dev_g1_multiples(plk_ctx* ctx, void* stream, const uint64_t base_xy[12],
 
 int plk_dev_coset_ntt(plk_ctx* ctx, void* stream, const uint64_t* const* in, size_t batch, size_t n_in, size_t N, const uint64_t shift[4],
                       int inverse, uint64_t* const* out) {
-  int rc = use_device(ctx);
+  int rc = use_stream(ctx, (hipStream_t)stream);
   if (rc) return rc;
   if (!in || !out) return fail(ctx, PLK_ERR_ARG, "null pointer table");
   for (size_t done = 0; done < batch; done += NTT_MAX_BATCH) {
@@ -1525,7 +1585,7 @@ int plk_dev_coset_ntt(plk_ctx* ctx, void* stream, const uint64_t* const* in, siz
 
 int plk_dev_quotient(plk_ctx* ctx, void* stream, const uint64_t* const* numerators, size_t count, const uint64_t alpha[4], size_t n, size_t N,
                      const uint64_t shift[4], uint64_t* coeffs_out) {
-  int rc = use_device(ctx);
+  int rc = use_stream(ctx, (hipStream_t)stream);
   if (rc) return rc;
   return launch_quotient(ctx, (hipStream_t)stream, numerators, count, alpha, n, N, shift, coeffs_out);
 }
@@ -1533,14 +1593,14 @@ int plk_dev_quotient(plk_ctx* ctx, void* stream, const uint64_t* const* numerato
 int plk_dev_gate_table_fill(plk_ctx* ctx, void* stream, const uint8_t* row_ops, const uint64_t* const node_ids[4], size_t n,
                             const uint64_t* node_values, size_t n_values, const uint64_t default_val[4],
                             uint64_t* const wires_out[4], uint64_t* const sel_out[9]) {
-  int rc = use_device(ctx);
+  int rc = use_stream(ctx, (hipStream_t)stream);
   if (rc) return rc;
   if (!node_ids || !wires_out) return fail(ctx, PLK_ERR_ARG, "null pointer table");
   return launch_gate_table_fill(ctx, (hipStream_t)stream, row_ops, node_ids, n, node_values, n_values, default_val, wires_out, sel_out);
 }
 
 int plk_dev_sigma_table(plk_ctx* ctx, void* stream, const uint64_t* const node_ids[4], size_t n, uint64_t* const sigma_out[4]) {
-  int rc = use_device(ctx);
+  int rc = use_stream(ctx, (hipStream_t)stream);
   if (rc) return rc;
   if (!node_ids || !sigma_out) return fail(ctx, PLK_ERR_ARG, "null pointer table");
   return launch_sigma_table(ctx, (hipStream_t)stream, node_ids, n, sigma_out);
@@ -1548,7 +1608,7 @@ int plk_dev_sigma_table(plk_ctx* ctx, void* stream, const uint64_t* const node_i
 
 int plk_dev_gate_constraint_eval(plk_ctx* ctx, void* stream, const uint64_t* const wire_evals[4],
                                  const uint64_t* const sel_evals[9], size_t N, uint64_t* out) {
-  int rc = use_device(ctx);
+  int rc = use_stream(ctx, (hipStream_t)stream);
   if (rc) return rc;
   if (!wire_evals) return fail(ctx, PLK_ERR_ARG, "null pointer table");
   return launch_gate_eval(ctx, (hipStream_t)stream, wire_evals, sel_evals, N, out);
@@ -1557,7 +1617,7 @@ int plk_dev_gate_constraint_eval(plk_ctx* ctx, void* stream, const uint64_t* con
 int plk_dev_perm_constraint_eval(plk_ctx* ctx, void* stream, const uint64_t* z_evals, const uint64_t* const sigma_evals[4],
                                  const uint64_t* const wire_evals[4], size_t N, const uint64_t beta[4],
                                  const uint64_t gamma[4], size_t z_shift, uint64_t* out) {
-  int rc = use_device(ctx);
+  int rc = use_stream(ctx, (hipStream_t)stream);
   if (rc) return rc;
   if (!sigma_evals || !wire_evals) return fail(ctx, PLK_ERR_ARG, "null pointer table");
   return launch_perm_eval(ctx, (hipStream_t)stream, z_evals, sigma_evals, wire_evals, N, beta, gamma, z_shift, out);
@@ -1566,7 +1626,7 @@ int plk_dev_perm_constraint_eval(plk_ctx* ctx, void* stream, const uint64_t* z_e
 int plk_dev_perm_constraint_eval_range(plk_ctx* ctx, void* stream, const uint64_t* z_evals, const uint64_t* const sigma_evals[4],
                                        const uint64_t* const wire_evals[4], size_t count, size_t index0, const uint64_t beta[4],
                                        const uint64_t gamma[4], size_t z_shift, uint64_t* out) {
-  int rc = use_device(ctx);
+  int rc = use_stream(ctx, (hipStream_t)stream);
   if (rc) return rc;
   if (!sigma_evals || !wire_evals) return fail(ctx, PLK_ERR_ARG, "null pointer table");
   return launch_perm_eval(ctx, (hipStream_t)stream, z_evals, sigma_evals, wire_evals, count, beta, gamma, z_shift, out, index0, true);
@@ -1575,7 +1635,7 @@ int plk_dev_perm_constraint_eval_range(plk_ctx* ctx, void* stream, const uint64_
 int plk_dev_round23(plk_ctx* ctx, void* stream, const uint64_t* const wires[4], const uint64_t* const sel[9],
                     const uint64_t* const sigma[4], size_t n, size_t N, const uint64_t beta[4], const uint64_t gamma[4],
                     size_t z_shift, uint64_t* z_out, uint64_t* gate_out, uint64_t* perm_out) {
-  int rc = use_device(ctx);
+  int rc = use_stream(ctx, (hipStream_t)stream);
   if (rc) return rc;
   if (!wires || !sigma) return fail(ctx, PLK_ERR_ARG, "null pointer table");
   return launch_round23(ctx, (hipStream_t)stream, wires, sel, sigma, n, N, beta, gamma, z_shift, z_out, gate_out, perm_out);
@@ -1583,7 +1643,7 @@ int plk_dev_round23(plk_ctx* ctx, void* stream, const uint64_t* const wires[4], 
 
 int plk_dev_extend4(plk_ctx* ctx, void* stream, const uint64_t* const* cols, const uint32_t* kinds, size_t batch, size_t n,
                     uint64_t* const* coef_out, uint64_t* const* eval_out, size_t chunk, size_t chunk_stride, size_t halo) {
-  int rc = use_device(ctx);
+  int rc = use_stream(ctx, (hipStream_t)stream);
   if (rc) return rc;
   if (!cols || !eval_out) return fail(ctx, PLK_ERR_ARG, "null pointer table");
   for (size_t done = 0; done < batch; done += NTT_MAX_BATCH) {
@@ -1597,7 +1657,7 @@ int plk_dev_extend4(plk_ctx* ctx, void* stream, const uint64_t* const* cols, con
 
 int plk_dev_ntt_strided(plk_ctx* ctx, void* stream, const uint64_t* in, size_t in_stride, uint32_t kind, size_t count,
                         size_t n_in, size_t N, int inverse, uint64_t* out, size_t out_stride) {
-  int rc = use_device(ctx);
+  int rc = use_stream(ctx, (hipStream_t)stream);
   if (rc) return rc;
   if (count == 0) return PLK_OK;
   if (!out || (!in && n_in)) return fail(ctx, PLK_ERR_ARG, "null pointer");
@@ -1615,7 +1675,7 @@ int plk_dev_ntt_strided(plk_ctx* ctx, void* stream, const uint64_t* in, size_t i
 }
 
 int plk_dev_mul(plk_ctx* ctx, void* stream, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
-  int rc = use_device(ctx);
+  int rc = use_stream(ctx, (hipStream_t)stream);
   if (rc) return rc;
   if (n == 0) return PLK_OK;
   if (!a || !b || !out) return fail(ctx, PLK_ERR_ARG, "null pointer");
@@ -1627,7 +1687,7 @@ int plk_dev_mul(plk_ctx* ctx, void* stream, const uint64_t* a, const uint64_t* b
 
 int plk_dev_twiddle_block(plk_ctx* ctx, void* stream, size_t N, int inverse, int scale_by_inverse_n, size_t rows, size_t cols,
                           size_t row0, size_t col0, uint64_t* out) {
-  int rc = use_device(ctx), log_n;
+  int rc = use_stream(ctx, (hipStream_t)stream), log_n;
   if (rc) return rc;
   if ((rc = check_domain(ctx, N, &log_n))) return rc;
   if (rows * cols == 0) return PLK_OK;
@@ -1643,13 +1703,13 @@ int plk_dev_twiddle_block(plk_ctx* ctx, void* stream, size_t N, int inverse, int
 }
 
 int plk_dev_status(plk_ctx* ctx, void* stream) {
-  int rc = use_device(ctx);
+  int rc = use_stream(ctx, (hipStream_t)stream);
   if (rc) return rc;
   return fetch_status(ctx, (hipStream_t)stream);
 }
 
 int plk_dev_to_montgomery(plk_ctx* ctx, void* stream, const uint64_t* in, size_t n, uint64_t* out) {
-  int rc = use_device(ctx);
+  int rc = use_stream(ctx, (hipStream_t)stream);
   if (rc) return rc;
   if (n == 0) return PLK_OK;
   if (!in || !out) return fail(ctx, PLK_ERR_ARG, "null pointer");
@@ -1660,7 +1720,7 @@ int plk_dev_to_montgomery(plk_ctx* ctx, void* stream, const uint64_t* in, size_t
 }
 
 int plk_dev_from_montgomery(plk_ctx* ctx, void* stream, const uint64_t* in, size_t n, uint64_t* out) {
-  int rc = use_device(ctx);
+  int rc = use_stream(ctx, (hipStream_t)stream);
   if (rc) return rc;
   if (n == 0) return PLK_OK;
   if (!in || !out) return fail(ctx, PLK_ERR_ARG, "null pointer");
@@ -1675,7 +1735,7 @@ int plk_dev_from_montgomery(plk_ctx* ctx, void* stream, const uint64_t* in, size
 // ---------------------------------------------------------------------------- host API
 
 int plk_intt(plk_ctx* ctx, const uint64_t* evals, size_t evals_len, size_t domain_size, uint64_t* coeffs_out) {
-  int rc = use_device(ctx), log_n;
+  int rc = use_host_stream(ctx), log_n;
   if (rc) return rc;
   if ((rc = check_domain(ctx, domain_size, &log_n))) return rc;
   if (evals_len != domain_size) return fail(ctx, PLK_ERR_LENGTH, plk_strerror(PLK_ERR_LENGTH));
@@ -1692,16 +1752,23 @@ int plk_intt(plk_ctx* ctx, const uint64_t* evals, size_t evals_len, size_t domai
 }
 
 int plk_build_and_convert(plk_ctx* ctx, size_t domain_size, plk_builder_fn builder, void* user, uint64_t* coeffs_out) {
-  if (!ctx) return PLK_ERR_ARG;
+  int rc = use_host_stream(ctx), log_n;
+  if (rc) return rc;
   if (!builder || !coeffs_out) return fail(ctx, PLK_ERR_ARG, "null pointer");
-  std::vector<uint64_t> evals(domain_size * 4 + 4);
-  const size_t produced = builder(user, evals.data(), domain_size);
-  if (produced != domain_size) return fail(ctx, PLK_ERR_LENGTH, "Domain size and builder evaluations length should match");
-  return plk_intt(ctx, evals.data(), produced, domain_size, coeffs_out);
+  // the domain is checked before anything is sized by it: a bogus size must come back as a code, not as an
+  // exception leaving an extern "C" function
+  if ((rc = check_domain(ctx, domain_size, &log_n))) return rc;
+  uint64_t* evals = new (std::nothrow) uint64_t[domain_size * 4 + 4];
+  if (!evals) return fail(ctx, PLK_ERR_NOMEM, "no host memory for " + std::to_string(domain_size) + " evaluations");
+  const size_t produced = builder(user, evals, domain_size);
+  if (produced != domain_size) rc = fail(ctx, PLK_ERR_LENGTH, "Domain size and builder evaluations length should match");
+  else rc = plk_intt(ctx, evals, produced, domain_size, coeffs_out);
+  delete[] evals;
+  return rc;
 }
 
 int plk_ntt(plk_ctx* ctx, const uint64_t* coeffs, size_t n_coeffs, size_t domain_size, uint64_t* evals_out) {
-  int rc = use_device(ctx), log_n;
+  int rc = use_host_stream(ctx), log_n;
   if (rc) return rc;
   if ((rc = check_domain(ctx, domain_size, &log_n))) return rc;
   if (n_coeffs > domain_size) return fail(ctx, PLK_ERR_LENGTH, "more coefficients than domain points");
@@ -1720,7 +1787,7 @@ int plk_ntt(plk_ctx* ctx, const uint64_t* coeffs, size_t n_coeffs, size_t domain
 
 int plk_gate_polys(plk_ctx* ctx, const uint64_t* const wires[4], const uint64_t* const sel[9], size_t n, size_t domain_size,
                    uint64_t* const wires_out[4], uint64_t* const sel_out[9]) {
-  int rc = use_device(ctx), log_n;
+  int rc = use_host_stream(ctx), log_n;
   if (rc) return rc;
   if ((rc = check_domain(ctx, domain_size, &log_n))) return rc;
   if (n != domain_size) return fail(ctx, PLK_ERR_LENGTH, plk_strerror(PLK_ERR_LENGTH));
@@ -1746,7 +1813,7 @@ int plk_gate_polys(plk_ctx* ctx, const uint64_t* const wires[4], const uint64_t*
 
 int plk_gate_constraints(plk_ctx* ctx, const uint64_t* const wire_coeffs[4], const uint64_t* const sel_coeffs[9], size_t n_coeffs,
                          size_t N, uint64_t* out_host) {
-  int rc = use_device(ctx), log_n;
+  int rc = use_host_stream(ctx), log_n;
   if (rc) return rc;
   if ((rc = check_domain(ctx, N, &log_n))) return rc;
   if (n_coeffs > N) return fail(ctx, PLK_ERR_LENGTH, "more coefficients than domain points");
@@ -1775,7 +1842,7 @@ int plk_gate_constraints(plk_ctx* ctx, const uint64_t* const wire_coeffs[4], con
 
 int plk_grand_product(plk_ctx* ctx, const uint64_t* const wires[4], const uint64_t* const sigma[4], size_t n,
                       const uint64_t beta[4], const uint64_t gamma[4], uint64_t* z_out) {
-  int rc = use_device(ctx);
+  int rc = use_host_stream(ctx);
   if (rc) return rc;
   if (!wires || !sigma || !z_out) return fail(ctx, PLK_ERR_ARG, "null pointer");
   Staged st(ctx);
@@ -1794,7 +1861,7 @@ int plk_grand_product(plk_ctx* ctx, const uint64_t* const wires[4], const uint64
 }
 
 int plk_msm_set_bases(plk_ctx* ctx, const uint64_t* bases_host, size_t n) {
-  int rc = use_device(ctx);
+  int rc = use_host_stream(ctx);
   if (rc) return rc;
   if (!bases_host && n) return fail(ctx, PLK_ERR_ARG, "null pointer");
   if (n == 0) { msm_free_table(ctx); return PLK_OK; }
@@ -1808,7 +1875,7 @@ int plk_msm_set_bases(plk_ctx* ctx, const uint64_t* bases_host, size_t n) {
 }
 
 int plk_msm_g1(plk_ctx* ctx, const uint64_t* scalars_host, size_t n, uint64_t out_xy[12]) {
-  int rc = use_device(ctx);
+  int rc = use_host_stream(ctx);
   if (rc) return rc;
   if (!scalars_host && n) return fail(ctx, PLK_ERR_ARG, "null pointer");
   Staged st(ctx);
@@ -1838,7 +1905,7 @@ int plk_g1_sum(const uint64_t* points_xy, size_t count, uint64_t out_xy[12]) {
 }
 
 int plk_msm_g1_batch(plk_ctx* ctx, const uint64_t* const scalars_host[], size_t count, size_t n, uint64_t* out_xy) {
-  int rc = use_device(ctx);
+  int rc = use_host_stream(ctx);
   if (rc) return rc;
   if (!scalars_host && count) return fail(ctx, PLK_ERR_ARG, "null pointer");
   Staged st(ctx);
@@ -1853,7 +1920,7 @@ int plk_msm_g1_batch(plk_ctx* ctx, const uint64_t* const scalars_host[], size_t 
 }
 
 int plk_coset_ntt(plk_ctx* ctx, const uint64_t* in, size_t n_in, size_t domain_size, const uint64_t shift[4], int inverse, uint64_t* out) {
-  int rc = use_device(ctx);
+  int rc = use_host_stream(ctx);
   if (rc) return rc;
   if ((!in && n_in) || !out) return fail(ctx, PLK_ERR_ARG, "null pointer");
   Staged st(ctx);
@@ -1870,7 +1937,7 @@ int plk_coset_ntt(plk_ctx* ctx, const uint64_t* in, size_t n_in, size_t domain_s
 
 int plk_quotient(plk_ctx* ctx, const uint64_t* const* numerators, size_t count, const uint64_t alpha[4], size_t n, size_t N,
                  const uint64_t shift[4], uint64_t* coeffs_out) {
-  int rc = use_device(ctx);
+  int rc = use_host_stream(ctx);
   if (rc) return rc;
   if (!numerators || !coeffs_out) return fail(ctx, PLK_ERR_ARG, "null pointer");
   if (count == 0 || count > QT_MAX_NUMERATORS) return fail(ctx, PLK_ERR_ARG, "between 1 and 8 numerators");
@@ -1892,7 +1959,7 @@ int plk_quotient(plk_ctx* ctx, const uint64_t* const* numerators, size_t count, 
 int plk_gate_table_fill(plk_ctx* ctx, const uint8_t* row_ops, const uint64_t* const node_ids[4], size_t n,
                         const uint64_t* node_values, size_t n_values, const uint64_t default_val[4],
                         uint64_t* const wires_out[4], uint64_t* const sel_out[9]) {
-  int rc = use_device(ctx);
+  int rc = use_host_stream(ctx);
   if (rc) return rc;
   if (!node_ids || !wires_out) return fail(ctx, PLK_ERR_ARG, "null pointer");
   if (n == 0) return PLK_OK;
@@ -1919,7 +1986,7 @@ int plk_gate_table_fill(plk_ctx* ctx, const uint8_t* row_ops, const uint64_t* co
 }
 
 int plk_sigma_table(plk_ctx* ctx, const uint64_t* const node_ids[4], size_t n, uint64_t* const sigma_out[4]) {
-  int rc = use_device(ctx);
+  int rc = use_host_stream(ctx);
   if (rc) return rc;
   if (!node_ids || !sigma_out) return fail(ctx, PLK_ERR_ARG, "null pointer");
   if (n == 0) return PLK_OK;
@@ -1939,7 +2006,7 @@ int plk_sigma_table(plk_ctx* ctx, const uint64_t* const node_ids[4], size_t n, u
 int plk_perm_polys(plk_ctx* ctx, const uint64_t* const wires[4], const uint64_t* const sigma[4], size_t n, size_t domain_size,
                    const uint64_t beta[4], const uint64_t gamma[4], uint64_t* const sigma_coeffs_out[4], uint64_t* z_coeffs_out,
                    uint64_t* z_last_out) {
-  int rc = use_device(ctx), log_n;
+  int rc = use_host_stream(ctx), log_n;
   if (rc) return rc;
   if ((rc = check_domain(ctx, domain_size, &log_n))) return rc;
   if (n != domain_size) return fail(ctx, PLK_ERR_LENGTH, plk_strerror(PLK_ERR_LENGTH));
@@ -1971,7 +2038,7 @@ int plk_perm_polys(plk_ctx* ctx, const uint64_t* const wires[4], const uint64_t*
 int plk_perm_constraints(plk_ctx* ctx, const uint64_t* z_coeffs, const uint64_t* const sigma_coeffs[4],
                          const uint64_t* const wire_coeffs[4], size_t n_coeffs, size_t N, const uint64_t beta[4],
                          const uint64_t gamma[4], size_t z_shift, uint64_t* out_host) {
-  int rc = use_device(ctx), log_n;
+  int rc = use_host_stream(ctx), log_n;
   if (rc) return rc;
   if ((rc = check_domain(ctx, N, &log_n))) return rc;
   if (n_coeffs > N) return fail(ctx, PLK_ERR_LENGTH, "more coefficients than domain points");
@@ -1998,7 +2065,7 @@ int plk_perm_constraints(plk_ctx* ctx, const uint64_t* z_coeffs, const uint64_t*
 int plk_round23(plk_ctx* ctx, const uint64_t* const wires[4], const uint64_t* const sel[9], const uint64_t* const sigma[4], size_t n,
                 size_t N, const uint64_t beta[4], const uint64_t gamma[4], size_t z_shift, uint64_t* z_out, uint64_t* gate_out,
                 uint64_t* perm_out) {
-  int rc = use_device(ctx), l1, l2;
+  int rc = use_host_stream(ctx), l1, l2;
   if (rc) return rc;
   if ((rc = check_domain(ctx, n, &l1))) return rc;
   if ((rc = check_domain(ctx, N, &l2))) return rc;

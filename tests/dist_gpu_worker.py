@@ -34,6 +34,22 @@ def main():
             got = pdist.four_step_ntt(to_device(x[lo:hi], d), N, eng, inverse=inverse)
             assert np.array_equal(to_host(got), want[lo:hi]), (log_n, inverse)
 
+    # a size past the CPU oracle's comfort: the sharded transform against the library's direct transform of the whole
+    # vector (itself checked against the oracle up to 2^18 and by closed forms beyond), both output layouts
+    N = 1 << 20
+    x = synth.random_elements(778, N)
+    lo, hi = rank * N // world, (rank + 1) * N // world
+    direct = eng.ntt_batch([to_device(x, d)], N)[0]
+    shard = to_device(x[lo:hi], d)
+    got = pdist.four_step_ntt(shard, N, eng)
+    assert torch.equal(got, direct[lo:hi]), "four-step at 2^20, natural order"
+    blk = pdist.four_step_ntt(shard, N, eng, natural_output=False)            # [my k1][k2] = X[k1 + N1 k2]
+    N1, N2 = pdist.split_domain(N)
+    r1 = N1 // world
+    assert torch.equal(blk, direct.view(N2, N1, 4)[:, rank * r1:(rank + 1) * r1].permute(1, 0, 2)), "four-step at 2^20, transposed output"
+    assert torch.equal(pdist.four_step_ntt(got, N, eng, inverse=True), shard), "four-step at 2^20, inverse"
+    del direct, blk, got
+
     for rows_n in (1 << 12, 3001):               # even and uneven row blocks
         cc = synth.make_circuit(1 << 12, circuit_id=5)
         w_h = [w[:rows_n] for w in cc.table.wires()]

@@ -92,6 +92,25 @@ def test_round23_2_20(prover, big):
         assert synth.mont_to_ints(g_h[4 * r:4 * r + 1])[0] == po.gate_expression(kind, a, b, cc, o)
 
 
+def test_batch_of_2_18_circuits_through_one_context(prover):
+    """The shape of the proof-throughput mode (64 circuits of n = 2^18 dealt to 8 GPUs = 8 per GPU): eight DIFFERENT
+    circuits back to back through one context and one shared set of output buffers, nothing synchronised between
+    them but the copy of the results; every output compared in full with the C restatement."""
+    n, N = 1 << 18, 1 << 20
+    circuits = [synth.make_circuit(n, circuit_id=100 + i) for i in range(8)]
+    dcs = [prover.upload(c) for c in circuits]
+    out = (prover.empty(n + 1), prover.empty(N), prover.empty(N))
+    got = []
+    for dc in dcs:
+        prover.round23(dc, N, out=out)
+        got.append([t.clone() for t in out])          # stream-ordered copies; the next call overwrites `out`
+    prover.status()
+    co.set_num_threads(min(co.num_threads(), 16))
+    for c, (z, g, e) in zip(circuits, got):
+        zr, gr, er = co.round23(c.table.wires(), c.table.selectors, c.perm.columns(), N, c.beta, c.gamma)
+        assert np.array_equal(to_host(z), zr) and np.array_equal(to_host(g), gr) and np.array_equal(to_host(e), er)
+
+
 def test_device_constraint_kernels_match_host_entry_points(prover):
     """plk_dev_* element-wise entry points on columns that already sit in HBM."""
     n, N = 1 << 12, 1 << 14
