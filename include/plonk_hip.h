@@ -287,14 +287,15 @@ int plk_dev_grand_product(plk_ctx* ctx, void* stream, const uint64_t* const wire
 
 /* plk_dev_grand_product for callers that cannot allocate (code under HIP graph capture, tight serving loops,
  * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same z_out (n + 1 elements),
- * same deferred status through plk_dev_status, same kernels; the per-row terms and per-block products go to a fixed
- * array inside the library's code object (PLK_NOALLOC_MAX_ROWS rows: 4 MiB + 4 KiB per GPU, held until the process
- * ends) instead of the context's grow-only workspace, so no call allocates or frees anything.  n above
- * PLK_NOALLOC_MAX_ROWS is PLK_ERR_ARG, and so is a call between plk_profile_begin and plk_profile_end (per-launch
- * events are allocated there).  All contexts on one GPU share that GPU's array: calls that may overlap on one GPU
- * (two streams, two contexts, two processes do NOT share it) race and must be ordered by the caller.  Nothing is
- * carried from one call to the next: every word the kernels read from the array was written earlier in the same call. */
-#define PLK_NOALLOC_MAX_ROWS ((size_t)1 << 16)
+ * same deferred status through plk_dev_status, same kernels; the per-block products that the kernels hand to one
+ * another go to a fixed array inside the library's code object (one element per 1024 rows, PLK_NOALLOC_MAX_ROWS
+ * rows at most: 32 KiB per GPU, held until the process ends) instead of the context's grow-only workspace, so no
+ * call allocates or frees anything.  n above PLK_NOALLOC_MAX_ROWS is PLK_ERR_ARG, and so is a call between
+ * plk_profile_begin and plk_profile_end (per-launch events are allocated there).  All contexts on one GPU share
+ * that GPU's array: calls that may overlap on one GPU (two contexts on two streams; two processes do NOT share
+ * it) race and must be ordered by the caller.  Nothing is carried from one call to the next: every word the
+ * kernels read from the array was written earlier in the same call. */
+#define PLK_NOALLOC_MAX_ROWS ((size_t)1 << 20)
 int plk_dev_grand_product_noalloc(plk_ctx* ctx, void* stream, const uint64_t* const wires[PLK_NUM_WIRES],
                                   const uint64_t* const sigma[PLK_NUM_WIRES], size_t n,
                                   const uint64_t beta[4], const uint64_t gamma[4], uint64_t* z_out);

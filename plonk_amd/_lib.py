@@ -29,7 +29,7 @@ MAX_BATCH = 24
 INPUT_FIELD = 0
 INPUT_U64 = 1
 NO_WIRE = (1 << 64) - 1
-NOALLOC_MAX_ROWS = 1 << 16
+NOALLOC_MAX_ROWS = 1 << 20
 
 u64p = C.POINTER(C.c_uint64)
 u64pp = C.POINTER(u64p)

@@ -33,7 +33,7 @@ namespace {
 
 constexpr size_t ELEM = 32;  // bytes per field element
 
-// The grand product's intermediate arrays: per-row terms and per-block products (grand_product.cuh).
+// Intermediate arrays of the row-range grand product: per-row terms and per-block products (grand_product.cuh).
 struct GpScratch {
   uint64_t *num = nullptr, *den = nullptr;   // rows elements each
   uint64_t *bn = nullptr, *bd = nullptr;     // one element per block of GP_BLOCK_ROWS rows
@@ -59,9 +59,9 @@ struct NttPlan {
 // code object instead of workspace slots.  Every GPU the library runs on holds its own copy, at its own address,
 // until the process ends.  In host code `scratch` is only a handle for hipGetSymbolAddress; the address the
 // kernels get is looked up once per device in plk_ctx_create and kept in the context.
-constexpr size_t NOALLOC_MAX_ROWS = size_t(1) << 16;
+constexpr size_t NOALLOC_MAX_ROWS = size_t(1) << 20;
 constexpr size_t NOALLOC_MAX_BLOCKS = (NOALLOC_MAX_ROWS + GP_BLOCK_ROWS - 1) / GP_BLOCK_ROWS;
-constexpr size_t NOALLOC_SCRATCH_BYTES = (2 * NOALLOC_MAX_ROWS + 2 * NOALLOC_MAX_BLOCKS) * ELEM;   // 4 MiB + 4 KiB
+constexpr size_t NOALLOC_SCRATCH_BYTES = NOALLOC_MAX_BLOCKS * ELEM;   // one block ratio per GP_BLOCK_ROWS rows: 32 KiB
 static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
 
 // Copies between ordinary (pageable) host memory and the device.  hipMemcpy stages such copies through one
@@ -522,7 +522,7 @@ int status_reset(plk_ctx* ctx, hipStream_t s) {
 // the whole circuit and the inversion is done here; otherwise the range's numerator and denominator
 // products are written to totals[0..1] (device) and gp_apply_carries must run before gp_finish.
 int gp_local(plk_ctx* ctx, hipStream_t s, const uint64_t* const wires[4], const uint64_t* const sigma[4], size_t n, size_t first,
-             size_t rows, const uint64_t beta_[4], const uint64_t gamma_[4], uint64_t* totals, const GpScratch* fixed = nullptr) {
+             size_t rows, const uint64_t beta_[4], const uint64_t gamma_[4], uint64_t* totals) {
   if (!beta_ || !gamma_) return fail(ctx, PLK_ERR_ARG, "null pointer");
   if (rows == 0 || first > n || rows > n - first) return fail(ctx, PLK_ERR_ARG, "row range outside the circuit");
   const Fe beta = fe_from_limbs64(beta_), gamma = fe_from_limbs64(gamma_);
@@ -535,9 +535,7 @@ int gp_local(plk_ctx* ctx, hipStream_t s, const uint64_t* const wires[4], const 
   }
   const size_t nb = (rows + GP_BLOCK_ROWS - 1) / GP_BLOCK_ROWS;
   GpScratch sc;
-  if (fixed) {
-    sc = *fixed;
-  } else {   // grow-only workspace slots of the context
+  {   // grow-only workspace slots of the context
     void *num, *den, *bn, *bd;
     int rc;
     if ((rc = ws_get(ctx, "gp_num", rows * ELEM, &num))) return rc;
@@ -587,8 +585,10 @@ int gp_finish(plk_ctx* ctx, hipStream_t s, uint64_t* z_after, uint64_t* z0) {
   return PLK_OK;
 }
 
+// The whole-circuit grand product, one pass over the columns (grand_product.cuh): z_out receives n + 1 elements.
+// `fixed` = a caller-provided array for the block ratios (one element per block) instead of a workspace slot.
 int launch_grand_product(plk_ctx* ctx, hipStream_t s, const uint64_t* const wires[4], const uint64_t* const sigma[4],
-                         size_t n, const uint64_t beta_[4], const uint64_t gamma_[4], uint64_t* z_out, const GpScratch* fixed = nullptr) {
+                         size_t n, const uint64_t beta_[4], const uint64_t gamma_[4], uint64_t* z_out, uint64_t* fixed = nullptr) {
   if (!z_out || !beta_ || !gamma_) return fail(ctx, PLK_ERR_ARG, "null pointer");
   if (n == 0) {  // z = [1]
     const Fe one = fe_one();
@@ -596,9 +596,43 @@ int launch_grand_product(plk_ctx* ctx, hipStream_t s, const uint64_t* const wire
     HIP_TRY(ctx, hipStreamSynchronize(s));
     return PLK_OK;
   }
-  int rc;
-  if ((rc = gp_local(ctx, s, wires, sigma, n, 0, n, beta_, gamma_, nullptr, fixed))) return rc;
-  return gp_finish(ctx, s, z_out + 4, z_out);
+  const Fe beta = fe_from_limbs64(beta_), gamma = fe_from_limbs64(gamma_);
+  if (!fe_is_canonical(beta) || !fe_is_canonical(gamma)) return fail(ctx, PLK_ERR_ARG, "beta/gamma not reduced mod p");
+  GpCols cols{};
+  for (int k = 0; k < 4; ++k) {
+    if (!wires[k] || !sigma[k]) return fail(ctx, PLK_ERR_ARG, "null column pointer");
+    cols.v[k] = wires[k];
+    cols.sigma[k] = sigma[k];
+  }
+  const size_t nb = (n + GP_BLOCK_ROWS - 1) / GP_BLOCK_ROWS;
+  if (nb > 0xffffffffull) return fail(ctx, PLK_ERR_ARG, "too many rows");
+  uint64_t* ratio = fixed;
+  if (!ratio) {
+    void* p;
+    int rc = ws_get(ctx, "gp_ratio", nb * ELEM, &p);
+    if (rc) return rc;
+    ratio = (uint64_t*)p;
+  }
+  const Fe beta_r2 = fe_mul(beta, fe_r2());
+  {
+    ProfScope ps(ctx, s, "gp_local_z_kernel", 320.0 * (double)n, 24.0 * (double)n);   // 4 values + 4 indices + 4 gathers in, z out
+    hipLaunchKernelGGL(gp_local_z_kernel, dim3((unsigned)nb), dim3(GP_THREADS), 0, s, cols, (uint64_t)n, beta, gamma, beta_r2,
+                       z_out + 4, z_out, ratio, ctx->status_dev);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  if (nb > 1) {
+    {
+      ProfScope ps(ctx, s, "gp_ratio_scan_kernel", 0.0);
+      hipLaunchKernelGGL(gp_ratio_scan_kernel, dim3(1), dim3(GP_SCAN_THREADS), 0, s, ratio, (uint32_t)nb);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    {
+      ProfScope ps(ctx, s, "gp_apply_kernel", 0.0, (double)n);
+      hipLaunchKernelGGL(gp_apply_kernel, dim3((unsigned)(nb - 1)), dim3(GP_THREADS), 0, s, z_out + 4, (uint64_t)n, (const uint64_t*)ratio);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  return PLK_OK;
 }
 
 int launch_gate_eval(plk_ctx* ctx, hipStream_t s, const uint64_t* const w[4], const uint64_t* const sel[9], size_t N,
@@ -1355,9 +1389,9 @@ int plk_ctx_create(int device, plk_ctx** out) {
   CTX_TRY(hipGetSymbolAddress((void**)&ctx->noalloc_ptr, HIP_SYMBOL(scratch)));
   {
     hipFuncAttributes fa;
-    CTX_TRY(hipFuncGetAttributes(&fa, (const void*)gp_terms_kernel));
-    CTX_TRY(hipFuncGetAttributes(&fa, (const void*)gp_block_scan_kernel));
-    CTX_TRY(hipFuncGetAttributes(&fa, (const void*)gp_finish_kernel));
+    CTX_TRY(hipFuncGetAttributes(&fa, (const void*)gp_local_z_kernel));
+    CTX_TRY(hipFuncGetAttributes(&fa, (const void*)gp_ratio_scan_kernel));
+    CTX_TRY(hipFuncGetAttributes(&fa, (const void*)gp_apply_kernel));
   }
   CTX_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES));
   CTX_TRY(hipFuncSetAttribute((const void*)ntt_final_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES));
@@ -1506,15 +1540,9 @@ int plk_dev_grand_product_noalloc(plk_ctx* ctx, void* stream, const uint64_t* co
     return fail(ctx, PLK_ERR_ARG, "plk_dev_grand_product_noalloc takes at most " + std::to_string(NOALLOC_MAX_ROWS) + " rows, got " +
                                       std::to_string(n) + ": use plk_dev_grand_product");
   if (ctx->profiling) return fail(ctx, PLK_ERR_ARG, "plk_dev_grand_product_noalloc is not available between plk_profile_begin/end (events are allocated there)");
-  // the fixed array, cut as [num | den | block numerators | block denominators]; every word a kernel reads here was
-  // written by an earlier kernel of this call, so nothing has to be cleared between calls
-  GpScratch sc;
-  unsigned char* base = ctx->noalloc_ptr;
-  sc.num = (uint64_t*)base;
-  sc.den = (uint64_t*)(base + NOALLOC_MAX_ROWS * ELEM);
-  sc.bn = (uint64_t*)(base + 2 * NOALLOC_MAX_ROWS * ELEM);
-  sc.bd = (uint64_t*)(base + (2 * NOALLOC_MAX_ROWS + NOALLOC_MAX_BLOCKS) * ELEM);
-  return launch_grand_product(ctx, (hipStream_t)stream, wires, sigma, n, beta, gamma, z_out, &sc);
+  // the fixed array holds the block ratios, one element per block of GP_BLOCK_ROWS rows; every word a kernel reads
+  // there was written by an earlier kernel of the same call, so nothing has to be cleared between calls
+  return launch_grand_product(ctx, (hipStream_t)stream, wires, sigma, n, beta, gamma, z_out, (uint64_t*)ctx->noalloc_ptr);
 }
 
 int plk_dev_grand_product_local(plk_ctx* ctx, void* stream, const uint64_t* const wires[4], const uint64_t* const sigma[4], size_t n,

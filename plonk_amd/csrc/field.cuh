@@ -232,11 +232,14 @@ __host__ __device__ __forceinline__ int bitlen4(const uint64_t x[4]) {
   return 0;
 }
 
-// bits [s, s + 64) of x (zero beyond bit 255)
+// bits [s, s + 64) of x (zero beyond bit 255).  The limb is picked by selects, not by indexing: a run-time index
+// would move the four-limb arrays of the caller from registers to scratch memory, hundreds of cycles per access.
 __host__ __device__ __forceinline__ uint64_t bits_from(const uint64_t x[4], int s) {
   const int limb = s >> 6, off = s & 63;
-  uint64_t v = x[limb] >> off;
-  if (off && limb + 1 < 4) v |= x[limb + 1] << (64 - off);
+  const uint64_t lo = limb == 0 ? x[0] : (limb == 1 ? x[1] : (limb == 2 ? x[2] : x[3]));
+  const uint64_t hi = limb == 0 ? x[1] : (limb == 1 ? x[2] : (limb == 2 ? x[3] : 0));
+  uint64_t v = lo >> off;
+  if (off) v |= hi << (64 - off);
   return v;
 }
 
@@ -322,6 +325,180 @@ __host__ __device__ inline Fe fe_inverse_bingcd(const Fe& x) {
   }
   Fe r;
   for (int i = 0; i < 4; ++i) { r.l[2 * i] = (uint32_t)v[i]; r.l[2 * i + 1] = (uint32_t)(v[i] >> 32); }
+  return r;
+}
+
+// ---- the same batched binary GCD on 32-bit limbs, the form the GPU runs fast ------------------------------------
+// One lane computes one inverse, so its latency is what counts (a block of the grand product waits for it).  Against
+// fe_inverse_bingcd: 32-bit limbs and factors (a 64-bit product on this GPU is ~10 instructions, a 32 x 32 + 64
+// multiply-add is one), 30 steps per round so that the factors fit 32-bit integers, runs of even steps taken at once
+// (count of trailing zeros), every array index a compile-time constant (nothing lives in scratch memory), one
+// conditional subtraction after the Montgomery step.  Same result: the inverse is unique.
+namespace gcd32 {
+
+constexpr int K = 30;   // steps per round; |f| + |g| <= 2^30 for both rows of the step matrix
+
+// r[0..8] = x[0..7] * m
+__host__ __device__ __forceinline__ void mul_small(const uint32_t x[8], uint32_t m, uint32_t r[9]) {
+  uint64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { c += (uint64_t)x[i] * m; r[i] = (uint32_t)c; c >>= 32; }
+  r[8] = (uint32_t)c;
+}
+
+// r += t (9 limbs), returns the carry out
+__host__ __device__ __forceinline__ uint32_t add9(uint32_t r[9], const uint32_t t[9]) {
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { const uint64_t s = (uint64_t)r[i] + t[i] + c; r[i] = (uint32_t)s; c = (uint32_t)(s >> 32); }
+  return c;
+}
+
+// r -= t (9 limbs), returns the borrow out
+__host__ __device__ __forceinline__ uint32_t sub9(uint32_t r[9], const uint32_t t[9]) {
+  uint32_t b = 0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { const uint64_t d = (uint64_t)r[i] - t[i] - b; r[i] = (uint32_t)d; b = (uint32_t)(d >> 63); }
+  return b;
+}
+
+__host__ __device__ __forceinline__ void neg9(uint32_t r[9]) {
+  uint32_t c = 1;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { const uint64_t s = (uint64_t)(~r[i]) + c; r[i] = (uint32_t)s; c = (uint32_t)(s >> 32); }
+}
+
+// out <- |f x + g y| / 2^K (exact); returns true if f x + g y was negative
+__host__ __device__ __forceinline__ bool lincomb_div(uint32_t out[8], const uint32_t x[8], int32_t f, const uint32_t y[8], int32_t g) {
+  uint32_t r[9], t[9];
+  mul_small(x, (uint32_t)(f < 0 ? -f : f), r);
+  mul_small(y, (uint32_t)(g < 0 ? -g : g), t);
+  bool negative = f < 0;
+  if ((f < 0) == (g < 0)) {
+    add9(r, t);
+  } else if (sub9(r, t)) {         // |f| x < |g| y: the sum has the sign of g
+    neg9(r);
+    negative = g < 0;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) out[i] = (r[i] >> K) | (r[i + 1] << (32 - K));
+  return negative;
+}
+
+// out <- (f u + g v) / 2^K mod p for u, v in [0, p); p = 1 mod 2^32, so the Montgomery factor is -t mod 2^K
+__host__ __device__ __forceinline__ void lincomb_mod(uint32_t out[8], const uint32_t u[8], int32_t f, const uint32_t v[8], int32_t g) {
+  uint32_t a[8], b[8], r[9], t[9];
+  {   // a negative factor: p - value instead
+    uint32_t bo = 0, bo2 = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint64_t d = (uint64_t)Field::P[i] - u[i] - bo; bo = (uint32_t)(d >> 63);
+      a[i] = f < 0 ? (uint32_t)d : u[i];
+      const uint64_t e = (uint64_t)Field::P[i] - v[i] - bo2; bo2 = (uint32_t)(e >> 63);
+      b[i] = g < 0 ? (uint32_t)e : v[i];
+    }
+  }
+  mul_small(a, (uint32_t)(f < 0 ? -f : f), r);
+  mul_small(b, (uint32_t)(g < 0 ? -g : g), t);
+  add9(r, t);                                              // below 2^K p
+  const uint32_t m = (0u - r[0]) & ((1u << K) - 1);
+  {
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { c += (uint64_t)Field::P[i] * m; t[i] = (uint32_t)c; c >>= 32; }
+    t[8] = (uint32_t)c;
+  }
+  add9(r, t);                                              // a multiple of 2^K, below 2^(K+1) p
+  uint32_t o[8], d[8], bo = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = (r[i] >> K) | (r[i + 1] << (32 - K));     // below 2 p
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { const uint64_t e = (uint64_t)o[i] - Field::P[i] - bo; d[i] = (uint32_t)e; bo = (uint32_t)(e >> 63); }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) out[i] = bo ? o[i] : d[i];
+}
+
+// the two 32-bit limbs that start at limb `limb` (limbs beyond the eighth read as zero), picked by selects
+__host__ __device__ __forceinline__ uint64_t window(const uint32_t x[8], int limb) {
+  uint32_t lo = x[0], hi = x[1];
+#pragma unroll
+  for (int i = 1; i < 8; ++i) {
+    lo = limb == i ? x[i] : lo;
+    hi = limb == i ? (i + 1 < 8 ? x[i + 1] : 0u) : hi;
+  }
+  return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+
+__host__ __device__ __forceinline__ int ctz64(uint64_t x) {   // x != 0
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __ffsll((unsigned long long)x) - 1;
+#else
+  return __builtin_ctzll(x);
+#endif
+}
+
+}  // namespace gcd32
+
+__host__ __device__ inline Fe fe_inverse_gcd32(const Fe& x) {
+  using namespace gcd32;
+  if (fe_is_zero(x)) return x;
+  uint32_t a[8], b[8], u[8], v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { a[i] = x.l[i]; b[i] = Field::P[i]; u[i] = Field::R2[i]; v[i] = 0; }   // x = a R: R^2 / x = R / a
+  // invariants: a = u x / R^2, b = v x / R^2 (mod p); gcd(a, b) = 1; ends with a = 0, b = 1
+  for (int round = 0; round < 40; ++round) {
+    uint32_t any = 0, top = 0; int hi = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { any |= a[i]; const uint32_t c = a[i] | b[i]; if (c) { top = c; hi = i; } }
+    if (!any) break;
+    // n = bit length of max(a, b); approximations: the top 34 bits above the low K bits (exact values if n <= 64)
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int n = 32 * hi + 32 - __clz((int)top);
+#else
+    const int n = 32 * hi + 32 - __builtin_clz(top);
+#endif
+    uint64_t xa, xb;
+    if (n <= 64) {
+      xa = (uint64_t)a[0] | ((uint64_t)a[1] << 32); xb = (uint64_t)b[0] | ((uint64_t)b[1] << 32);
+    } else {
+      const int s = n - 34, limb = s >> 5, off = s & 31;          // bits [s, s + 34): off + 34 <= 65, so a third limb may be touched
+      const uint64_t wa = window(a, limb), wb = window(b, limb);
+      uint64_t ta = wa >> off, tb = wb >> off;
+      if (off > 30) {   // the 34 bits reach into limb + 2
+        const uint64_t wa2 = window(a, limb + 1), wb2 = window(b, limb + 1);
+        ta = (wa2 << (32 - off)) | (ta & ((1ull << (64 - off)) - 1)); tb = (wb2 << (32 - off)) | (tb & ((1ull << (64 - off)) - 1));
+      }
+      ta &= (1ull << 34) - 1; tb &= (1ull << 34) - 1;
+      xa = (ta << K) | (a[0] & ((1u << K) - 1));
+      xb = (tb << K) | (b[0] & ((1u << K) - 1));
+    }
+    int32_t f0 = 1, g0 = 0, f1 = 0, g1 = 1;
+    for (int done = 0; done < K;) {
+      if (xa & 1) {
+        if (xa < xb) {
+          const uint64_t tx = xa; xa = xb; xb = tx;
+          int32_t ts = f0; f0 = f1; f1 = ts;
+          ts = g0; g0 = g1; g1 = ts;
+        }
+        xa -= xb; f0 -= f1; g0 -= g1;
+      }
+      // xa is even now: take the run of even steps at once (xa = 0 ends the round's useful work: shift all the rest)
+      int t = xa ? ctz64(xa) : K;
+      if (t > K - done) t = K - done;
+      xa >>= t; f1 <<= t; g1 <<= t;
+      done += t;
+    }
+    uint32_t na[8], nb[8], nu[8], nv[8];
+    if (lincomb_div(na, a, f0, b, g0)) { f0 = -f0; g0 = -g0; }
+    if (lincomb_div(nb, a, f1, b, g1)) { f1 = -f1; g1 = -g1; }
+    lincomb_mod(nu, u, f0, v, g0);
+    lincomb_mod(nv, u, f1, v, g1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a[i] = na[i]; b[i] = nb[i]; u[i] = nu[i]; v[i] = nv[i]; }
+  }
+  Fe r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.l[i] = v[i];
   return r;
 }
 

@@ -73,6 +73,114 @@ __device__ __forceinline__ Fe block_scan_mul(Fe v, Fe* lds, Fe* total) {
   return has_carry ? fe_mul(v, carry) : v;
 }
 
+// ---- whole-circuit form: one pass over the columns ------------------------------------------------------------
+//
+// z[j+1] = prod_{i<=j} num_i / den_i.  With the rows cut into blocks of GP_BLOCK_ROWS and r_b = (product of the
+// block's numerators) / (product of its denominators),
+//   z[j+1] = C_b * L_j,   C_b = prod_{b' < b} r_b',   L_j = prod_{i <= j, i in block b} num_i / den_i.
+// gp_local_z_kernel reads the columns ONCE, keeps the per-row terms in registers, inverts ONE value per block
+// (Montgomery's batch-inversion identity inside the block: 1 / prod_{i<=j} den_i = (1 / D_b) * prod_{i>j} den_i)
+// and writes L_j where z[j+1] goes, plus r_b; gp_ratio_scan_kernel (one workgroup) turns the r_b into the C_b;
+// gp_apply_kernel multiplies each block of z by its C_b.  Per row: 288 bytes in, 32 out, then 32 in and out again
+// for the carry - against 288 + 64 out, 64 + 32 back in of the three-kernel form below (kept for row ranges on
+// several GPUs, which need the products apart) - and no single-workgroup inversion on the critical path.
+
+// num_j and den_j of one row (one for a row beyond the circuit), failures recorded with their row
+__device__ __forceinline__ void gp_row_terms(const GpCols& cols, uint64_t n, uint64_t j, const Fe& beta, const Fe& gamma, const Fe& beta_r2,
+                                             GpStatus* status, Fe& nj, Fe& dj) {
+  nj = fe_one(); dj = fe_one();
+  if (j >= n) return;
+  Fe jraw = fe_zero(); jraw.l[0] = (uint32_t)j; jraw.l[1] = (uint32_t)(j >> 32);
+  const Fe bj_g = fe_add(fe_mul(jraw, beta_r2), gamma);          // beta * F::from(j) + gamma
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const Fe v = fe_load(cols.v[k], j);
+    uint64_t sg = cols.sigma[k][j];
+    if (sg >= n) { atomicMin(&status->bad_sigma_row, (unsigned long long)j); sg = 0; }
+    const Fe vs = fe_load(cols.v[k], sg);
+    const Fe tn = fe_add(fe_add(v, fe_mul(beta, vs)), gamma);
+    const Fe td = fe_add(v, bj_g);
+    nj = (k == 0) ? tn : fe_mul(nj, tn);
+    dj = (k == 0) ? td : fe_mul(dj, td);
+  }
+  if (fe_is_zero(dj)) atomicMin(&status->zero_den_row, (unsigned long long)j);
+}
+
+// Kernel A: local quotient products L_j -> z_after[j] (= z[j+1] up to the block carry), block ratios r_b -> ratio[b].
+__global__ __launch_bounds__(GP_THREADS, 4) void gp_local_z_kernel(GpCols cols, uint64_t n, Fe beta, Fe gamma, Fe beta_r2,
+                                                                uint64_t* z_after, uint64_t* z0, uint64_t* ratio, GpStatus* status) {
+  __shared__ Fe lds[GP_THREADS / 64];
+  __shared__ Fe edge[GP_THREADS / 64];
+  __shared__ Fe inv_total;
+  const uint64_t row0 = ((uint64_t)blockIdx.x * GP_THREADS + threadIdx.x) * GP_ITEMS;
+  // the four rows are written out with named values (no array, no loop): the terms must stay in registers from
+  // here to the stores at the end
+  static_assert(GP_ITEMS == 4, "gp_local_z_kernel spells out four rows per thread");
+  Fe n0, n1, n2, n3, d0, d1, d2, d3;
+  gp_row_terms(cols, n, row0 + 0, beta, gamma, beta_r2, status, n0, d0);
+  gp_row_terms(cols, n, row0 + 1, beta, gamma, beta_r2, status, n1, d1);
+  gp_row_terms(cols, n, row0 + 2, beta, gamma, beta_r2, status, n2, d2);
+  gp_row_terms(cols, n, row0 + 3, beta, gamma, beta_r2, status, n3, d3);
+  // thread-local inclusive prefix of the numerators, inclusive suffix of the denominators
+  n1 = fe_mul(n0, n1); n2 = fe_mul(n1, n2); n3 = fe_mul(n2, n3);
+  d2 = fe_mul(d3, d2); d1 = fe_mul(d2, d1); d0 = fe_mul(d1, d0);
+  Fe tot_n, tot_d;
+  const Fe inc_n = block_scan_mul<GP_THREADS, false>(n3, lds, &tot_n);
+  const Fe inc_d = block_scan_mul<GP_THREADS, true>(d0, lds, &tot_d);
+  if (threadIdx.x == 0) {
+    const Fe inv = fe_inverse_gcd32(tot_d);                  // zero stays zero; the status word carries the error
+    inv_total = inv;
+    fe_store(ratio, blockIdx.x, fe_mul(tot_n, inv));
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  Fe ex_n = fe_shfl(inc_n, (lane - 1) & 63);
+  Fe ex_d = fe_shfl(inc_d, (lane + 1) & 63);
+  if (lane == 63) lds[wave] = inc_n;
+  if (lane == 0) edge[wave] = inc_d;
+  __syncthreads();
+  if (lane == 0) ex_n = wave == 0 ? fe_one() : lds[wave - 1];
+  if (lane == 63) ex_d = wave == GP_THREADS / 64 - 1 ? fe_one() : edge[wave + 1];
+  const Fe cd = fe_mul(ex_d, inv_total);
+  // L_j = (prefix of numerators up to j) * (suffix of denominators after j) / (all denominators of the block)
+  if (row0 + 0 < n) fe_store(z_after, row0 + 0, fe_mul(fe_mul(ex_n, n0), fe_mul(d1, cd)));
+  if (row0 + 1 < n) fe_store(z_after, row0 + 1, fe_mul(fe_mul(ex_n, n1), fe_mul(d2, cd)));
+  if (row0 + 2 < n) fe_store(z_after, row0 + 2, fe_mul(fe_mul(ex_n, n2), fe_mul(d3, cd)));
+  if (row0 + 3 < n) fe_store(z_after, row0 + 3, fe_mul(fe_mul(ex_n, n3), cd));
+  if (z0 && blockIdx.x == 0 && threadIdx.x == 0) fe_store(z0, 0, fe_one());
+}
+
+// Kernel B (one workgroup): exclusive prefix products of the nb block ratios, in place.
+__global__ __launch_bounds__(GP_SCAN_THREADS) void gp_ratio_scan_kernel(uint64_t* ratio, uint32_t nb) {
+  __shared__ Fe lds[GP_SCAN_THREADS / 64];
+  __shared__ Fe edge[GP_SCAN_THREADS / 64];
+  const uint32_t per = (nb + GP_SCAN_THREADS - 1) / GP_SCAN_THREADS;
+  const uint32_t lo = min(threadIdx.x * per, nb), hi = min(lo + per, nb);
+  Fe prod = fe_one();
+  for (uint32_t b = lo; b < hi; ++b) prod = fe_mul(prod, fe_load(ratio, b));
+  Fe tot;
+  const Fe inc = block_scan_mul<GP_SCAN_THREADS, false>(prod, lds, &tot);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  Fe run = fe_shfl(inc, (lane - 1) & 63);
+  if (lane == 63) edge[wave] = inc;
+  __syncthreads();
+  if (lane == 0) run = wave == 0 ? fe_one() : edge[wave - 1];
+  for (uint32_t b = lo; b < hi; ++b) { const Fe t = fe_load(ratio, b); fe_store(ratio, b, run); run = fe_mul(run, t); }
+}
+
+// Kernel C: z_after[j] *= carry[block of j]; block 0's carry is one and its rows are left alone.
+__global__ __launch_bounds__(GP_THREADS) void gp_apply_kernel(uint64_t* z_after, uint64_t n, const uint64_t* carry) {
+  const uint32_t b = blockIdx.x + 1;
+  const Fe c = fe_load(carry, b);
+  const uint64_t base = (uint64_t)b * GP_BLOCK_ROWS;
+#pragma unroll
+  for (int it = 0; it < GP_ITEMS; ++it) {
+    const uint64_t j = base + (uint64_t)it * GP_THREADS + threadIdx.x;     // consecutive threads, consecutive rows
+    if (j < n) fe_store(z_after, j, fe_mul(fe_load(z_after, j), c));
+  }
+}
+
+// ---- row-range form (rows split over several GPUs): terms, block products, carries, finish ---------------------
+
 // Kernel 1: per-row numerator / denominator terms and per-block products, for the rows
 // [first, first + rows) of an n-row circuit (the whole circuit: first = 0, rows = n).  num/den/block_*
 // are indexed from the range's first row; the gathers reach any row of the columns.
@@ -134,7 +242,7 @@ __global__ __launch_bounds__(GP_SCAN_THREADS) void gp_block_scan_kernel(uint64_t
   const Fe inc_d = block_scan_mul<GP_SCAN_THREADS, true>(pd, lds, &tot_d);
   if (threadIdx.x == 0) {
     if (totals) { fe_store(totals, 0, tot_n); fe_store(totals, 1, tot_d); inv_total = fe_one(); }
-    else inv_total = fe_inverse_bingcd(tot_d);               // zero stays zero; the status word carries the error
+    else inv_total = fe_inverse_gcd32(tot_d);               // zero stays zero; the status word carries the error
   }
   __syncthreads();
   // exclusive carries of this thread's chunk: inclusive result with the own chunk divided out is
@@ -163,21 +271,19 @@ __global__ __launch_bounds__(GP_THREADS) void gp_finish_kernel(const uint64_t* n
   __shared__ Fe lds[GP_THREADS / 64];
   __shared__ Fe edge[GP_THREADS / 64];
   const uint64_t row0 = ((uint64_t)blockIdx.x * GP_THREADS + threadIdx.x) * GP_ITEMS;
-  Fe nv[GP_ITEMS], dv[GP_ITEMS];
-#pragma unroll
-  for (int it = 0; it < GP_ITEMS; ++it) {
-    const uint64_t j = row0 + it;
-    nv[it] = j < n ? fe_load(num, j) : fe_one();
-    dv[it] = j < n ? fe_load(den, j) : fe_one();
-  }
+  // named values, not arrays: the terms stay in registers (see gp_local_z_kernel)
+  static_assert(GP_ITEMS == 4, "gp_finish_kernel spells out four rows per thread");
+  const Fe one = fe_one();
+  Fe n0 = row0 + 0 < n ? fe_load(num, row0 + 0) : one, d0 = row0 + 0 < n ? fe_load(den, row0 + 0) : one;
+  Fe n1 = row0 + 1 < n ? fe_load(num, row0 + 1) : one, d1 = row0 + 1 < n ? fe_load(den, row0 + 1) : one;
+  Fe n2 = row0 + 2 < n ? fe_load(num, row0 + 2) : one, d2 = row0 + 2 < n ? fe_load(den, row0 + 2) : one;
+  Fe n3 = row0 + 3 < n ? fe_load(num, row0 + 3) : one, d3 = row0 + 3 < n ? fe_load(den, row0 + 3) : one;
   // thread-local inclusive prefix of num, inclusive suffix of den
-#pragma unroll
-  for (int it = 1; it < GP_ITEMS; ++it) nv[it] = fe_mul(nv[it - 1], nv[it]);
-#pragma unroll
-  for (int it = GP_ITEMS - 2; it >= 0; --it) dv[it] = fe_mul(dv[it + 1], dv[it]);
+  n1 = fe_mul(n0, n1); n2 = fe_mul(n1, n2); n3 = fe_mul(n2, n3);
+  d2 = fe_mul(d3, d2); d1 = fe_mul(d2, d1); d0 = fe_mul(d1, d0);
   Fe tot;
-  const Fe inc_n = block_scan_mul<GP_THREADS, false>(nv[GP_ITEMS - 1], lds, &tot);
-  const Fe inc_d = block_scan_mul<GP_THREADS, true>(dv[0], lds, &tot);
+  const Fe inc_n = block_scan_mul<GP_THREADS, false>(n3, lds, &tot);
+  const Fe inc_d = block_scan_mul<GP_THREADS, true>(d0, lds, &tot);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // exclusive carries: previous thread's inclusive prefix, next thread's inclusive suffix
   Fe ex_n = fe_shfl(inc_n, (lane - 1) & 63);
@@ -190,14 +296,10 @@ __global__ __launch_bounds__(GP_THREADS) void gp_finish_kernel(const uint64_t* n
   const Fe cn = fe_mul(ex_n, fe_load(block_num_ex, blockIdx.x));   // includes 1/D
   const Fe cd = fe_mul(ex_d, fe_load(block_den_ex, blockIdx.x));
   // z[j+1] = (cn * prefix_num_j) * (suffix_den_{j+1} * cd)
-#pragma unroll
-  for (int it = 0; it < GP_ITEMS; ++it) {
-    const uint64_t j = row0 + it;
-    if (j >= n) break;
-    const Fe p = fe_mul(cn, nv[it]);
-    const Fe s = it + 1 < GP_ITEMS ? fe_mul(dv[it + 1], cd) : cd;
-    fe_store(z_after, j, fe_mul(p, s));
-  }
+  if (row0 + 0 < n) fe_store(z_after, row0 + 0, fe_mul(fe_mul(cn, n0), fe_mul(d1, cd)));
+  if (row0 + 1 < n) fe_store(z_after, row0 + 1, fe_mul(fe_mul(cn, n1), fe_mul(d2, cd)));
+  if (row0 + 2 < n) fe_store(z_after, row0 + 2, fe_mul(fe_mul(cn, n2), fe_mul(d3, cd)));
+  if (row0 + 3 < n) fe_store(z_after, row0 + 3, fe_mul(fe_mul(cn, n3), cd));
   if (z0 && blockIdx.x == 0 && threadIdx.x == 0) fe_store(z0, 0, fe_one());
 }
 
@@ -216,7 +318,7 @@ __global__ __launch_bounds__(GP_THREADS) void gp_carry_kernel(const uint64_t* to
       if (g < mine) cn = fe_mul(cn, fe_load(totals_all, 2 * g));
       if (g > mine) cd = fe_mul(cd, d);
     }
-    carry[0] = fe_mul(cn, fe_inverse_bingcd(all));
+    carry[0] = fe_mul(cn, fe_inverse_gcd32(all));
     carry[1] = cd;
   }
   __syncthreads();

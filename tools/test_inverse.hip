@@ -29,9 +29,9 @@ static Fe random_fe(int kind) {
 int main() {
   long bad = 0, total = 0;
   auto check = [&](const Fe& x) {
-    const Fe a = fe_inverse_bingcd(x), b = fe_inverse_eea(x);
+    const Fe a = fe_inverse_bingcd(x), b = fe_inverse_eea(x), c = fe_inverse_gcd32(x);
     ++total;
-    if (!fe_eq(a, b) || !fe_eq(fe_mul(a, x), fe_one()) || !below_p(a)) {
+    if (!fe_eq(a, b) || !fe_eq(a, c) || !fe_eq(fe_mul(a, x), fe_one()) || !below_p(a)) {
       if (bad++ < 5) { printf("MISMATCH x="); for (int i = 7; i >= 0; --i) printf("%08x", x.l[i]); printf("\n"); }
     }
   };
@@ -43,8 +43,8 @@ int main() {
   s.l[0] -= 1; check(s);
   for (int b = 1; b < 255; ++b) { Fe t = fe_zero(); t.l[b / 32] = 1u << (b % 32); check(t); }   // powers of two
   for (long i = 0; i < 100000; ++i) check(random_fe((int)(i % 3)));
-  const Fe z = fe_inverse_bingcd(fe_zero());
-  if (!fe_is_zero(z)) { ++bad; printf("inverse of zero is not zero\n"); }
+  const Fe z = fe_inverse_bingcd(fe_zero()), z2 = fe_inverse_gcd32(fe_zero());
+  if (!fe_is_zero(z) || !fe_is_zero(z2)) { ++bad; printf("inverse of zero is not zero\n"); }
   printf("%ld values, %ld mismatches\n", total, bad);
   return bad != 0;
 }
