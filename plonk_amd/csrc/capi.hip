@@ -136,6 +136,7 @@ struct plk_ctx {
   bool have_last_stream = false;
   hipEvent_t ev_order = nullptr;
   std::map<std::pair<int, int>, NttPlan> plans;  // (log_n, inverse)
+  DevBuf master_sh[2];                           // in-tile twiddle pairs for the precomputed-quotient product, per direction
   std::map<std::string, DevBuf> ws;              // grow-only workspace slots
   struct PowTable { DevBuf lo, hi; size_t hi_count = 0; };
   std::map<std::array<uint64_t, 4>, PowTable> powers;   // g -> tables of g^j (coset transforms)
@@ -285,6 +286,28 @@ int get_plan(plk_ctx* ctx, int log_n, bool inverse, hipStream_t s, NttPlan** out
   if ((rc = alloc_table(ctx, plan.lo, 1ull << lo_bits, w, 0, one, s))) return rc;
   if ((rc = alloc_table(ctx, plan.hi, 1ull << (log_n - lo_bits), w, lo_bits, one, s))) return rc;
   plan.tab.master = (const uint32_t*)plan.master.p;
+  {
+    // The in-tile twiddles once more, as (constant, quotient) pairs for shoup29_x2 (fr29.cuh): omega_{2^11}^e as a
+    // canonical integer and floor(that * 2^261 / p).  They depend on the direction only and are built on the host
+    // (a thousand long divisions), once per context.
+    DevBuf& sh = ctx->master_sh[inverse ? 1 : 0];
+    if (!sh.p) {
+      const size_t count = size_t(1) << (NTT_MASTER_LOG - 1);
+      std::vector<uint32_t> rec(count * 2 * TW_WORDS, 0);
+      Fe raw_one = fe_zero(); raw_one.l[0] = 1;
+      Fe cur = fe_one();
+      for (size_t e = 0; e < count; ++e) {
+        const Fe plain = fe_mul(cur, raw_one);               // out of Montgomery form: the integer omega^e, below p
+        const F9 w9 = f9_from_fe(plain), q9 = f9_shoup_quotient_host(plain);
+        for (int i = 0; i < 9; ++i) { rec[(2 * e) * TW_WORDS + i] = w9.l[i]; rec[(2 * e + 1) * TW_WORDS + i] = q9.l[i]; }
+        cur = fe_mul(cur, wm);
+      }
+      HIP_TRY(ctx, hipMalloc(&sh.p, rec.size() * 4));
+      sh.cap = rec.size() * 4;
+      HIP_TRY(ctx, hipMemcpy(sh.p, rec.data(), rec.size() * 4, hipMemcpyHostToDevice));
+    }
+    plan.tab.master_sh = (const uint32_t*)sh.p;
+  }
   plan.tab.tw_lo = (const uint32_t*)plan.lo.p;
   plan.tab.tw_hi = (const uint32_t*)plan.hi.p;
   {
@@ -1406,6 +1429,7 @@ void plk_ctx_destroy(plk_ctx* ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   (void)hipDeviceSynchronize();
   for (auto& kv : ctx->plans) free_plan_tables(kv.second);
+  for (auto& b : ctx->master_sh) if (b.p) (void)hipFree(b.p);
   for (auto& kv : ctx->ws) if (kv.second.p) (void)hipFree(kv.second.p);
   msm_free_table(ctx);
   if (ctx->msm_sums) (void)hipHostFree(ctx->msm_sums);

@@ -218,6 +218,85 @@ __device__ __forceinline__ void mont29_x2(const F9& a1, const F9& b1, const F9& 
 }
 #undef PLK_PIN
 
+// ---- product by a constant with a precomputed quotient (Shoup / Harvey style) ---------------------------------
+// For a constant w < p the table holds w itself (canonical, 9 limbs) and wq = floor(w * 2^261 / p).  Then for any
+// a < 2^261:   q = floor(a * wq / 2^261)  satisfies  a w / p - a / 2^261 - 1 < q <= a w / p,
+// so r = a w - q p lies in [0, (1 + a / 2^261) p): below 1.91 p for a < 64 p, the bound mont29 gives as well.
+// r is computed modulo 2^261 (it is below 2^261): the low nine columns of a * w + q * (2^261 - p).
+// Of a * wq only columns 7..16 are formed: the dropped columns 0..6 hold at most 7 products each, below 2^60.4 at
+// weights up to 2^174, less than 2^238 in all, which lowers q by less than 2^-23 (covered by the slack above:
+// 64 p < 0.907 * 2^261).
+// Cost: 53 + 45 + 45 = 143 multiply-adds against mont29's 153; measured alone 7 % more products per second at
+// the transform kernels' occupancy (tools/ubench_shoup.hip).  The result is a * w with no Montgomery factor, so
+// data in the library's R = 2^256 form stays in that form.
+namespace f9c {
+// limb i of 2^261 - p: the limb-wise complement of p plus one; p's limb 0 is 1, so no carry travels
+constexpr uint32_t pbar_limb(int i) { return i == 0 ? M29 : M29 - kp_limb29(1, i); }
+}  // namespace f9c
+
+#define PLK_PIN(x) asm volatile("" : "+v"(x))
+// Two independent products in lockstep (as mont29_x2): a1 * w1 -> r1, a2 * w2 -> r2; wq1 / wq2 the quotient records.
+// Input bounds: a lazy with limbs < 1.3 * 2^31 and value < 64 p; w, wq normalised.  Output: normalised, < 1.91 p.
+__device__ __forceinline__ void shoup29_x2(const F9& a1, const F9& w1, const F9& wq1, const F9& a2, const F9& w2, const F9& wq2,
+                                           F9& r1, F9& r2) {
+  uint64_t acc1 = 0, acc2 = 0;
+  uint32_t q1[9], q2[9];
+#pragma unroll
+  for (int i = 0; i <= 7; ++i) { acc1 += (uint64_t)a1.l[i] * wq1.l[7 - i]; acc2 += (uint64_t)a2.l[i] * wq2.l[7 - i]; PLK_PIN(acc1); PLK_PIN(acc2); }
+  acc1 >>= 29; acc2 >>= 29;
+#pragma unroll
+  for (int i = 0; i <= 8; ++i) { acc1 += (uint64_t)a1.l[i] * wq1.l[8 - i]; acc2 += (uint64_t)a2.l[i] * wq2.l[8 - i]; PLK_PIN(acc1); PLK_PIN(acc2); }
+  acc1 >>= 29; acc2 >>= 29;
+#pragma unroll
+  for (int k = 9; k < 17; ++k) {
+#pragma unroll
+    for (int i = k - 8; i <= 8; ++i) { acc1 += (uint64_t)a1.l[i] * wq1.l[k - i]; acc2 += (uint64_t)a2.l[i] * wq2.l[k - i]; PLK_PIN(acc1); PLK_PIN(acc2); }
+    q1[k - 9] = (uint32_t)acc1 & M29; q2[k - 9] = (uint32_t)acc2 & M29;
+    acc1 >>= 29; acc2 >>= 29;
+  }
+  q1[8] = (uint32_t)acc1; q2[8] = (uint32_t)acc2;
+  acc1 = 0; acc2 = 0;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+#pragma unroll
+    for (int i = 0; i <= k; ++i) { acc1 += (uint64_t)a1.l[i] * w1.l[k - i]; acc2 += (uint64_t)a2.l[i] * w2.l[k - i]; PLK_PIN(acc1); PLK_PIN(acc2); }
+#pragma unroll
+    for (int i = 0; i <= k; ++i) { acc1 += (uint64_t)q1[i] * f9c::pbar_limb(k - i); acc2 += (uint64_t)q2[i] * f9c::pbar_limb(k - i); PLK_PIN(acc1); PLK_PIN(acc2); }
+    r1.l[k] = (uint32_t)acc1 & M29; r2.l[k] = (uint32_t)acc2 & M29;
+    acc1 >>= 29; acc2 >>= 29;
+  }
+}
+#undef PLK_PIN
+
+// host: the quotient record of a canonical constant, wq = floor(w * 2^261 / p), by bit-at-a-time long division
+// (table set-up only: a thousand records per plan)
+inline F9 f9_shoup_quotient_host(const Fe& w_canonical) {
+  uint32_t rem[9] = {0}, quo[17] = {0};
+  uint32_t p9[9];
+  for (int i = 0; i < 8; ++i) p9[i] = Field::P[i];
+  p9[8] = 0;
+  for (int b = 255 + 261; b >= 0; --b) {
+    const int src = b - 261;    // bit of w that sits at position b of w << 261
+    uint32_t carry = (src >= 0) ? (w_canonical.l[src >> 5] >> (src & 31)) & 1u : 0u;
+    for (int i = 0; i < 9; ++i) { const uint32_t nc = rem[i] >> 31; rem[i] = (rem[i] << 1) | carry; carry = nc; }
+    bool ge = true;
+    for (int i = 8; i >= 0; --i) if (rem[i] != p9[i]) { ge = rem[i] > p9[i]; break; }
+    if (ge) {
+      uint64_t bo = 0;
+      for (int i = 0; i < 9; ++i) { const uint64_t d = (uint64_t)rem[i] - p9[i] - bo; rem[i] = (uint32_t)d; bo = (d >> 63) & 1; }
+      quo[b >> 5] |= 1u << (b & 31);
+    }
+  }
+  F9 r;
+  for (int i = 0; i < 9; ++i) {
+    const int bit = 29 * i, wd = bit >> 5, o = bit & 31;
+    uint64_t x = quo[wd];
+    if (wd + 1 < 17) x |= (uint64_t)quo[wd + 1] << 32;
+    r.l[i] = (uint32_t)(x >> o) & M29;
+  }
+  return r;
+}
+
 // a * b * 2^-256 mod p: the library's own Montgomery product on 29-bit limbs, for point-wise kernels whose two
 // operands are both data.  Eight columns are reduced as in mont29; of the ninth only the low 24 bits are
 // cleared (8 * 29 + 24 = 256), and the columns above it are re-cut 24 bits higher.

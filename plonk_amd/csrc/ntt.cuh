@@ -52,6 +52,9 @@ struct NttBatch {
 // records (value * 2^261 mod p as 9 limbs, fr29.cuh).
 struct NttTables {
   const uint32_t* master;  // omega_{2^11}^e (or its inverse), e < 2^10
+  // the same constants for the precomputed-quotient product (fr29.cuh, shoup29_x2): record 2e = omega_{2^11}^e as a
+  // canonical integer, record 2e + 1 = floor(that * 2^261 / p); nullptr = not built
+  const uint32_t* master_sh;
   const uint32_t* tw_hi;   // omega_N^(e << lo_bits), e < 2^(logN - lo_bits)
   const uint32_t* tw_hi_scaled;  // same times 1/N (inverse, first inter-pass twiddle); == tw_hi for forward
   const uint32_t* tw_lo;   // omega_N^e, e < 2^lo_bits
@@ -115,9 +118,14 @@ __device__ __forceinline__ F9 load_input(const uint64_t* in, uint64_t idx, bool 
 //     products, issued as two interleaved pairs); an odd stage left over runs two butterflies per thread;
 //   * the last step hands its results to `store` instead of writing them back.
 // Outputs are lazy: limbs < 1.3 * 2^31, value < (4 + 2 log_r) p.
-template <class Load, class Store>
-__device__ __forceinline__ void tile_transform(const Tile& t, int log_r, int log_c, const uint32_t* master, bool quarter,
-                                               Load load, Store store) {
+//
+// SH = true: the butterfly products of the later steps use the precomputed-quotient form (shoup29_x2, 143
+// multiply-adds instead of 153) with twiddle pairs (w, wq) from `master_sh`; the caller picks it when the pairs of
+// this radix fit the LDS twiddle area (radix <= 2^7).  Same values, same bounds (both products return < 1.91 p).
+struct TwPair { F9 w, q; };
+template <bool SH, class Load, class Store>
+__device__ __forceinline__ void tile_transform(const Tile& t, int log_r, int log_c, const uint32_t* master, const uint32_t* master_sh,
+                                               bool quarter, Load load, Store store) {
   const int cmask = (1 << log_c) - 1;
   if (log_r == 0) {
     for (int c = threadIdx.x; c <= cmask; c += NTT_THREADS) store(0, c, load(0, c));
@@ -135,12 +143,22 @@ __device__ __forceinline__ void tile_transform(const Tile& t, int log_r, int log
   // (first used after the barrier that ends the first step)
   const Tile ltw(reinterpret_cast<unsigned char*>(t.A) + (size_t)NTT_TILE * 36, 1 << NTT_LDS_TW_LOG);
   const bool tw_lds = log_r - 1 <= NTT_LDS_TW_LOG;
-  if (tw_lds && log_r > 2) {
+  constexpr int SH_SLOTS = 1 << (NTT_LDS_TW_LOG - 1);       // pairs that fit the LDS twiddle area
+  if (SH) {
+    if (log_r > 2) {
+      const int count = 1 << (log_r - 1);                    // <= SH_SLOTS, the caller's condition for SH
+      for (int j = threadIdx.x; j < 2 * count; j += NTT_THREADS) {
+        const int e = j >> 1, half = j & 1;
+        ltw.put(half * SH_SLOTS + e, f9_load_tw(master_sh, (((size_t)e << (NTT_MASTER_LOG - log_r)) << 1) + half));
+      }
+    }
+  } else if (tw_lds && log_r > 2) {
     const int count = 1 << (log_r - 1);
     for (int j = threadIdx.x; j < count; j += NTT_THREADS)
       ltw.put(j, f9_load_tw(master, (size_t)j << (NTT_MASTER_LOG - log_r)));
   }
   auto tw = [&](int idx) { return tw_lds ? ltw.get(idx) : f9_load_tw(master, (size_t)idx << (NTT_MASTER_LOG - log_r)); };
+  auto tw2 = [&](int idx) { TwPair r; r.w = ltw.get(idx); r.q = ltw.get(SH_SLOTS + idx); return r; };
   const int groups = 1 << (log_r + log_c - 2);
   const int quarter_rows = 1 << (log_r - 2);
 
@@ -181,13 +199,18 @@ __device__ __forceinline__ void tile_transform(const Tile& t, int log_r, int log
       const int i0 = ((q >> lh) << (lh + 2)) + j;
       const int e0 = (i0 << log_c) + c, step = h << log_c;
       const F9 x0 = t.get(e0), x1 = t.get(e0 + step), x2 = t.get(e0 + 2 * step), x3 = t.get(e0 + 3 * step);
-      const F9 w1 = tw(j << (log_r - 1 - lh));                                          // omega_{2h}^j
       F9 t1, t3;
-      mont29_x2(x1, w1, x3, w1, t1, t3);
+      if (SH) { const TwPair w1 = tw2(j << (log_r - 1 - lh)); shoup29_x2(x1, w1.w, w1.q, x3, w1.w, w1.q, t1, t3); }   // omega_{2h}^j
+      else { const F9 w1 = tw(j << (log_r - 1 - lh)); mont29_x2(x1, w1, x3, w1, t1, t3); }
       const F9 a0 = f9_add(x0, t1), a1 = f9_sub_q2(x0, t1), a2 = f9_add(x2, t3), a3 = f9_sub_q2(x2, t3);
-      const F9 w2 = tw(j << (log_r - 2 - lh)), w3 = tw((j + h) << (log_r - 2 - lh));     // omega_{4h}^j, omega_{4h}^(j+h)
-      F9 s2, s3;
-      mont29_x2(a2, w2, a3, w3, s2, s3);
+      F9 s2, s3;                                                                          // omega_{4h}^j, omega_{4h}^(j+h)
+      if (SH) {
+        const TwPair w2 = tw2(j << (log_r - 2 - lh)), w3 = tw2((j + h) << (log_r - 2 - lh));
+        shoup29_x2(a2, w2.w, w2.q, a3, w3.w, w3.q, s2, s3);
+      } else {
+        const F9 w2 = tw(j << (log_r - 2 - lh)), w3 = tw((j + h) << (log_r - 2 - lh));
+        mont29_x2(a2, w2, a3, w3, s2, s3);
+      }
       F9 y0 = f9_add(a0, s2), y2 = f9_sub_q2(a0, s2), y1 = f9_add(a1, s3), y3 = f9_sub_q2(a1, s3);
       f9_normalize(y0); f9_normalize(y1); f9_normalize(y2); f9_normalize(y3);
       if (last) { store(i0, c, y0); store(i0 + h, c, y1); store(i0 + 2 * h, c, y2); store(i0 + 3 * h, c, y3); }
@@ -214,7 +237,12 @@ __device__ __forceinline__ void tile_transform(const Tile& t, int log_r, int log
       const F9 xa = t.get((row[0] << log_c) + col[0]), xb = t.get((row[1] << log_c) + col[1]);
       const F9 ya = t.get(((row[0] + h) << log_c) + col[0]), yb = t.get(((row[1] + h) << log_c) + col[1]);
       F9 ta, tb;
-      mont29_x2(ya, tw(jj[0] << (log_r - 1 - lh)), yb, tw(jj[1] << (log_r - 1 - lh)), ta, tb);
+      if (SH) {
+        const TwPair wa = tw2(jj[0] << (log_r - 1 - lh)), wb = tw2(jj[1] << (log_r - 1 - lh));
+        shoup29_x2(ya, wa.w, wa.q, yb, wb.w, wb.q, ta, tb);
+      } else {
+        mont29_x2(ya, tw(jj[0] << (log_r - 1 - lh)), yb, tw(jj[1] << (log_r - 1 - lh)), ta, tb);
+      }
       store(row[0], col[0], f9_add(xa, ta)); store(row[0] + h, col[0], f9_sub_q2(xa, ta));
       if (second) { store(row[1], col[1], f9_add(xb, tb)); store(row[1] + h, col[1], f9_sub_q2(xb, tb)); }
     }
@@ -256,7 +284,7 @@ struct NttPassArgs {
 // cosets) run on one XCD at about the same time, so the inter-pass twiddle and prescale records
 // of that position, and in coset mode the input tile shared by a column's cosets, come from L2
 // instead of once per slot from memory.
-__global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const NttPassArgs a) {
+__global__ __launch_bounds__(NTT_THREADS, 4) void ntt_pass_kernel(const NttPassArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const Tile tile(lds_raw);
   uint32_t wg = blockIdx.x;
@@ -280,20 +308,23 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const NttPassArgs
   const uint32_t* full = a.tab.tw_full[a.pass];
   const int coset = a.cosets ? slot % a.cosets : 0;
   (void)elems;
-  tile_transform(
-      tile, log_r, log_c, a.tab.master, a.first && log_r >= 2 && (a.n_in << 2) <= (1ull << a.log_n),
+  const bool quarter = a.first && log_r >= 2 && (a.n_in << 2) <= (1ull << a.log_n);
+  auto load =
       [&](int r, int c) {   // row r of the digit this pass transforms: a run of 2^log_c consecutive elements per row
         const uint64_t idx = base + ((uint64_t)r << log_inner) + c;
         F9 v = load_input(in, idx, !(a.first && idx >= a.n_in), kind, a.tab.from_u64);
         if (a.first && a.cosets) v = mont29(v, f9_load_tw(a.prescale, ((uint64_t)coset << a.log_n) + idx));
         return v;
-      },
+      };
+  auto store =
       [&](int k, int c, const F9& v) {
         const uint64_t q = q0 + c;
         const F9 tw = full ? f9_load_tw(full, ((uint64_t)k << log_inner) + q)
                            : twiddle_two_level(hi, a.tab.tw_lo, a.tab.lo_bits, ((uint64_t)k * q) << shift);
         fe_store(out, base + ((uint64_t)k << log_inner) + c, fe_pack_f9(mont29(v, tw)));
-      });
+      };
+  if (a.tab.master_sh && log_r >= 3 && log_r <= NTT_LDS_TW_LOG) tile_transform<true>(tile, log_r, log_c, a.tab.master, a.tab.master_sh, quarter, load, store);
+  else tile_transform<false>(tile, log_r, log_c, a.tab.master, a.tab.master_sh, quarter, load, store);
 }
 
 struct NttFinalArgs {
@@ -316,7 +347,7 @@ struct NttFinalArgs {
 // Row o_c = (k1_0 + c) * R2 + k2 of the pass-major buffer feeds column c of the tile; a thread of the
 // first step reads its four elements of that row straight from memory (32-byte pieces; the row's
 // lines are shared by neighbouring waves of the workgroup through the vector cache).
-__global__ __launch_bounds__(NTT_THREADS) void ntt_final_kernel(const NttFinalArgs a) {
+__global__ __launch_bounds__(NTT_THREADS, 4) void ntt_final_kernel(const NttFinalArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const Tile tile(lds_raw);
   const int slot = blockIdx.y;   // slots share nothing here, so the plain 2-D order is kept
@@ -332,19 +363,22 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_final_kernel(const NttFinalAr
   const bool scaled = a.tab.scale != nullptr;
   F9 sc;
   if (scaled) sc = f9_load_tw(a.tab.scale, 0);
-  tile_transform(
-      tile, log_r, log_c, a.tab.master, a.first && log_r >= 2 && (a.n_in << 2) <= (1ull << a.log_n),
+  const bool quarter = a.first && log_r >= 2 && (a.n_in << 2) <= (1ull << a.log_n);
+  auto load =
       [&](int r, int c) {
         const uint64_t orow = ((k1_0 + c) << a.log_r2) + k2;
         const uint64_t idx = (orow << log_r) + r;
         F9 v = load_input(in, idx, !(a.first && idx >= a.n_in), kind, a.tab.from_u64);
         if (a.first && a.cosets) v = mont29(v, f9_load_tw(a.prescale, ((uint64_t)(slot % a.cosets) << a.log_n) + idx));
         return v;
-      },
+      };
+  auto store =
       [&](int k, int c, const F9& v) {
         const uint64_t dst = (k1_0 + c) + (k2 << a.log_r1) + ((uint64_t)k << (a.log_r1 + a.log_r2));
         fe_store(out, dst, fe_reduce_f9(scaled ? mont29(v, sc) : v));
-      });
+      };
+  if (a.tab.master_sh && log_r >= 3 && log_r <= NTT_LDS_TW_LOG) tile_transform<true>(tile, log_r, log_c, a.tab.master, a.tab.master_sh, quarter, load, store);
+  else tile_transform<false>(tile, log_r, log_c, a.tab.master, a.tab.master_sh, quarter, load, store);
 }
 
 // ---- table construction (device side, run once per plan)
