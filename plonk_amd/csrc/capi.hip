@@ -132,6 +132,9 @@ struct plk_ctx {
   // The workspace, the status word and the side stream are shared by every call on the context, so calls are
   // ordered one after another whatever stream they are given: when a device call arrives on another stream
   // than the previous one, the new stream first waits for an event recorded at the end of the old one.
+  // plk_round23 on host arrays: uploads, kernels and downloads overlap on streams of their own
+  hipStream_t copy_up = nullptr, copy_down = nullptr;
+  hipEvent_t ev_pipe[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipStream_t last_stream = nullptr;
   bool have_last_stream = false;
   hipEvent_t ev_order = nullptr;
@@ -703,6 +706,87 @@ int launch_perm_eval(plk_ctx* ctx, hipStream_t s, const uint64_t* z, const uint6
   return PLK_OK;
 }
 
+// Pieces of rounds 2+3 on the 4n-point domain seen as four cosets of the trace domain.  On coset 0 every column IS
+// its table (interpolation followed by evaluation at the same points is the identity), so only cosets 1..3 are
+// computed: three prescaled n-point transforms per column, kept coset-major in the workspace.
+// Column numbering inside the workspace: wires 0-3, selectors 4-12, sigma 13-16, z 17.
+struct R23Ws {
+  uint64_t *coef = nullptr, *eval = nullptr, *z = nullptr;
+  size_t n = 0, N = 0;
+  uint64_t* col_coef(int c) const { return coef + (size_t)c * n * 4; }
+  uint64_t* col_eval(int c) const { return eval + (size_t)c * N * 4; }
+  uint64_t* col_cos(int c) const { return eval + (size_t)c * 3 * n * 4; }   // planes 1..3 of column c
+};
+
+int r23_workspace(plk_ctx* ctx, size_t n, size_t N, uint64_t* z_out, R23Ws* ws) {
+  constexpr int NCOL = 18;
+  void *coef_p, *eval_p, *z_p;
+  int rc;
+  if ((rc = ws_get(ctx, "r23_coef", (size_t)NCOL * n * ELEM, &coef_p))) return rc;
+  if ((rc = ws_get(ctx, "r23_eval", (size_t)NCOL * N * ELEM, &eval_p))) return rc;
+  if ((rc = ws_get(ctx, "r23_z", (n + 1) * ELEM, &z_p))) return rc;
+  ws->coef = (uint64_t*)coef_p; ws->eval = (uint64_t*)eval_p; ws->z = z_out ? z_out : (uint64_t*)z_p;
+  ws->n = n; ws->N = N;
+  return PLK_OK;
+}
+
+// interpolation of m columns and their three coset transforms, into the workspace columns col_of[b]
+int r23_extend_group(plk_ctx* ctx, hipStream_t s, const R23Ws& ws, const uint64_t* const* cols, const uint32_t* kinds, const int* col_of,
+                     size_t m, const char* tmp_slot = "ntt_tmp") {
+  if (m == 0) return PLK_OK;
+  const uint64_t* in[NTT_MAX_BATCH]; uint64_t* out[NTT_MAX_BATCH];
+  int rc;
+  for (size_t b = 0; b < m; ++b) { in[b] = cols[b]; out[b] = ws.col_coef(col_of[b]); }
+  if ((rc = launch_ntt(ctx, s, in, kinds, m, ws.n, ws.n, true, out, 0, 0, 0, tmp_slot))) return rc;
+  for (size_t b = 0; b < m; ++b) { in[b] = ws.col_coef(col_of[b]); out[b] = ws.col_cos(col_of[b]); }
+  return launch_ntt(ctx, s, in, nullptr, m, ws.n, ws.n, false, out, 0, 0, 3, tmp_slot);
+}
+
+// grand product -> Z interpolation -> Z cosets (column 17)
+int r23_z_chain(plk_ctx* ctx, hipStream_t s, const R23Ws& ws, const uint64_t* const wires[4], const uint64_t* const sigma[4],
+                const uint64_t beta[4], const uint64_t gamma[4], hipEvent_t z_ready = nullptr) {
+  int rc;
+  if ((rc = launch_grand_product(ctx, s, wires, sigma, ws.n, beta, gamma, ws.z))) return rc;
+  if (z_ready) HIP_TRY(ctx, hipEventRecord(z_ready, s));
+  const uint64_t* zin[1] = {ws.z}; const uint32_t kind[1] = {NTT_IN_FIELD}; const int col[1] = {17};
+  return r23_extend_group(ctx, s, ws, zin, kind, col, 1, "ntt_tmp_aux");
+}
+
+int r23_gate(plk_ctx* ctx, hipStream_t s, const R23Ws& ws, const uint64_t* const wires[4], const uint64_t* const sel[9], uint64_t* gate_out) {
+  GateColsCoset g{};
+  int ncols = 5;
+  for (int k = 0; k < 4; ++k) { g.w0[k] = wires[k]; g.w[k] = ws.col_cos(k); }
+  for (int k = 0; k < 9; ++k) { const bool on = sel && sel[k]; g.s0[k] = on ? sel[k] : nullptr; g.s[k] = on ? ws.col_cos(4 + k) : nullptr; ncols += on; }
+  ProfScope ps(ctx, s, "gate_constraint_coset_kernel", 32.0 * ncols * (double)ws.N, 12.0 * (double)ws.N);
+  hipLaunchKernelGGL(gate_constraint_coset_kernel, dim3((unsigned)((ws.N + EW_THREADS - 1) / EW_THREADS)), dim3(EW_THREADS), 0, s, g,
+                     (uint64_t)ws.n, gate_out);
+  HIP_TRY(ctx, hipGetLastError());
+  return PLK_OK;
+}
+
+int r23_perm(plk_ctx* ctx, hipStream_t s, const R23Ws& ws, const uint64_t* const wires[4], const uint64_t* const sigma[4],
+             const uint64_t beta[4], const uint64_t gamma[4], size_t z_shift, uint64_t* perm_out) {
+  const Fe fb = fe_from_limbs64(beta), fg = fe_from_limbs64(gamma);
+  PermColsCoset pc{};
+  pc.z0 = ws.z; pc.z = ws.col_cos(17);
+  for (int k = 0; k < 4; ++k) { pc.sig0[k] = sigma[k]; pc.sig[k] = ws.col_cos(13 + k); pc.w0[k] = wires[k]; pc.w[k] = ws.col_cos(k); }
+  ProfScope ps(ctx, s, "perm_constraint_coset_kernel", 320.0 * (double)ws.N, 18.0 * (double)ws.N);
+  hipLaunchKernelGGL(perm_constraint_coset_kernel, dim3((unsigned)((ws.N + EW_THREADS - 1) / EW_THREADS)), dim3(EW_THREADS), 0, s, pc,
+                     (uint64_t)ws.n, fb, fg, fe_mul(fb, fe_r2()), (uint64_t)(z_shift % ws.N), perm_out);
+  HIP_TRY(ctx, hipGetLastError());
+  return PLK_OK;
+}
+
+bool r23_coset_form(size_t n, size_t N, int log_n) { return N == 4 * n && log_n >= 2 && log_n + 2 <= Field::TWO_ADICITY; }
+
+// Makes `s` wait for the side stream before the enclosing function returns, whatever happens in between.
+struct SideJoin {
+  plk_ctx* ctx; hipStream_t s, sa; bool recorded = false, joined = false;
+  void record() { if (!recorded) { (void)hipEventRecord(ctx->ev_join, sa); recorded = true; } }
+  void join() { record(); if (!joined) { (void)hipStreamWaitEvent(s, ctx->ev_join, 0); joined = true; } }
+  ~SideJoin() { join(); }
+};
+
 // Rounds 2+3 on device columns.  Workspace: 18 coefficient vectors (n) and 18 evaluation
 // vectors (N).  Column order inside the workspace: wires 0-3, selectors 4-12, sigma 13-16, z 17.
 int launch_round23(plk_ctx* ctx, hipStream_t s, const uint64_t* const wires[4], const uint64_t* const sel[9],
@@ -713,71 +797,30 @@ int launch_round23(plk_ctx* ctx, hipStream_t s, const uint64_t* const wires[4], 
   if ((rc = check_domain(ctx, N, &log_N))) return rc;
   if (n > N) return fail(ctx, PLK_ERR_LENGTH, "evaluation domain smaller than the trace");
   constexpr int NCOL = 18;
-  void *coef_p, *eval_p, *z_p;
-  if ((rc = ws_get(ctx, "r23_coef", (size_t)NCOL * n * ELEM, &coef_p))) return rc;
-  if ((rc = ws_get(ctx, "r23_eval", (size_t)NCOL * N * ELEM, &eval_p))) return rc;
-  if ((rc = ws_get(ctx, "r23_z", (n + 1) * ELEM, &z_p))) return rc;
-  uint64_t* coef = (uint64_t*)coef_p;
-  uint64_t* eval = (uint64_t*)eval_p;
-  uint64_t* z = z_out ? z_out : (uint64_t*)z_p;
+  R23Ws ws;
+  if ((rc = r23_workspace(ctx, n, N, z_out, &ws))) return rc;
+  uint64_t* z = ws.z;
 
   const uint64_t* in[NCOL]; uint64_t* out[NCOL]; uint32_t kinds[NCOL]; int col_of[NCOL]; size_t m = 0;
-  auto col_coef = [&](int c) { return coef + (size_t)c * n * 4; };
-  auto col_eval = [&](int c) { return eval + (size_t)c * N * 4; };
+  auto col_coef = [&](int c) { return ws.col_coef(c); };
+  auto col_eval = [&](int c) { return ws.col_eval(c); };
 
-  if (N == 4 * n && log_n >= 2 && log_n + 2 <= Field::TWO_ADICITY) {
-    // The 4n-point domain is four cosets of the trace domain.  On coset 0 every column IS its
-    // table (interpolation followed by evaluation at the same points is the identity), so only
-    // cosets 1..3 are computed: three prescaled n-point transforms per column, kept coset-major.
-    auto col_cos = [&](int c) { return eval + (size_t)c * 3 * n * 4; };   // planes 1..3 of column c
+  if (r23_coset_form(n, N, log_n)) {
     // Side stream: grand product -> Z interpolation -> Z cosets.  Its kernels are gather-, latency-
     // and launch-bound; they run beside the 17 other columns' transforms, which are VALU-bound.
     hipStream_t sa = ctx->aux;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, s));
     HIP_TRY(ctx, hipStreamWaitEvent(sa, ctx->ev_fork, 0));
-    // whatever happens below, `s` is made to wait for the side stream before this function returns
-    struct Join {
-      plk_ctx* ctx; hipStream_t s, sa; bool recorded = false, joined = false;
-      void record() { if (!recorded) { (void)hipEventRecord(ctx->ev_join, sa); recorded = true; } }
-      void join() { record(); if (!joined) { (void)hipStreamWaitEvent(s, ctx->ev_join, 0); joined = true; } }
-      ~Join() { join(); }
-    } side{ctx, s, sa};
-    if ((rc = launch_grand_product(ctx, sa, wires, sigma, n, beta, gamma, z))) return rc;
-    {
-      const uint64_t* zin[1] = {z}; uint64_t* zc[1] = {col_coef(17)}; uint64_t* ze[1] = {col_cos(17)};
-      if ((rc = launch_ntt(ctx, sa, zin, nullptr, 1, n, n, true, zc, 0, 0, 0, "ntt_tmp_aux"))) return rc;
-      const uint64_t* zci[1] = {col_coef(17)};
-      if ((rc = launch_ntt(ctx, sa, zci, nullptr, 1, n, n, false, ze, 0, 0, 3, "ntt_tmp_aux"))) return rc;
-    }
+    SideJoin side{ctx, s, sa};
+    if ((rc = r23_z_chain(ctx, sa, ws, wires, sigma, beta, gamma))) return rc;
     side.record();
     for (int k = 0; k < 4; ++k) { in[m] = wires[k]; kinds[m] = NTT_IN_FIELD; col_of[m] = k; ++m; }
     for (int k = 0; k < 9; ++k) if (sel && sel[k]) { in[m] = sel[k]; kinds[m] = NTT_IN_FIELD; col_of[m] = 4 + k; ++m; }
     for (int k = 0; k < 4; ++k) { in[m] = sigma[k]; kinds[m] = NTT_IN_U64; col_of[m] = 13 + k; ++m; }
-    for (size_t b = 0; b < m; ++b) out[b] = col_coef(col_of[b]);
-    if ((rc = launch_ntt(ctx, s, in, kinds, m, n, n, true, out))) return rc;
-    for (size_t b = 0; b < m; ++b) { in[b] = col_coef(col_of[b]); out[b] = col_cos(col_of[b]); }
-    if ((rc = launch_ntt(ctx, s, in, nullptr, m, n, n, false, out, 0, 0, 3))) return rc;
-    if (gate_out) {
-      GateColsCoset g{};
-      int ncols = 5;
-      for (int k = 0; k < 4; ++k) { g.w0[k] = wires[k]; g.w[k] = col_cos(k); }
-      for (int k = 0; k < 9; ++k) { const bool on = sel && sel[k]; g.s0[k] = on ? sel[k] : nullptr; g.s[k] = on ? col_cos(4 + k) : nullptr; ncols += on; }
-      ProfScope ps(ctx, s, "gate_constraint_coset_kernel", 32.0 * ncols * (double)N, 12.0 * (double)N);
-      hipLaunchKernelGGL(gate_constraint_coset_kernel, dim3((unsigned)((N + EW_THREADS - 1) / EW_THREADS)), dim3(EW_THREADS), 0, s, g,
-                         (uint64_t)n, gate_out);
-      HIP_TRY(ctx, hipGetLastError());
-    }
+    if ((rc = r23_extend_group(ctx, s, ws, in, kinds, col_of, m))) return rc;
+    if (gate_out && (rc = r23_gate(ctx, s, ws, wires, sel, gate_out))) return rc;
     side.join();
-    if (perm_out) {
-      const Fe fb = fe_from_limbs64(beta), fg = fe_from_limbs64(gamma);
-      PermColsCoset pc{};
-      pc.z0 = z; pc.z = col_cos(17);
-      for (int k = 0; k < 4; ++k) { pc.sig0[k] = sigma[k]; pc.sig[k] = col_cos(13 + k); pc.w0[k] = wires[k]; pc.w[k] = col_cos(k); }
-      ProfScope ps(ctx, s, "perm_constraint_coset_kernel", 320.0 * (double)N, 18.0 * (double)N);
-      hipLaunchKernelGGL(perm_constraint_coset_kernel, dim3((unsigned)((N + EW_THREADS - 1) / EW_THREADS)), dim3(EW_THREADS), 0, s, pc,
-                         (uint64_t)n, fb, fg, fe_mul(fb, fe_r2()), (uint64_t)(z_shift % N), perm_out);
-      HIP_TRY(ctx, hipGetLastError());
-    }
+    if (perm_out && (rc = r23_perm(ctx, s, ws, wires, sigma, beta, gamma, z_shift, perm_out))) return rc;
     return PLK_OK;
   }
 
@@ -1350,6 +1393,128 @@ int use_device(plk_ctx* ctx) {
   return PLK_OK;
 }
 
+// plk_round23 on the 4n-point domain with uploads, kernels and downloads overlapped.  The columns go up in the
+// order wires, selectors (three at a time), sigma; every group's transforms start when the group has arrived
+// (page-locked arrays: DMA on a copy stream, the kernels wait for its event; pageable arrays: the threaded copy
+// returns when the group is resident).  The gate constraints need wires and selectors only, so they run - and
+// their vector goes down - while sigma is still on its way up and being transformed; z goes down as soon as the
+// grand product has finished.  What remains exposed is the upload of the 13 + 4 columns and, at the end, the
+// permutation kernel and the download of its vector.
+int round23_host_pipelined(plk_ctx* ctx, const uint64_t* const wires[4], const uint64_t* const sel[9], const uint64_t* const sigma[4],
+                           size_t n, size_t N, const uint64_t beta[4], const uint64_t gamma[4], size_t z_shift, uint64_t* z_out,
+                           uint64_t* gate_out, uint64_t* perm_out) {
+  int rc;
+  hipStream_t s = ctx->stream, sa = ctx->aux, up = ctx->copy_up, down = ctx->copy_down;
+  enum { EV_W = 0, EV_S, EV_Z, EV_GATE, EV_PERM, EV_SEL0 };   // EV_SEL0 .. EV_SEL0 + 2
+  Staged st(ctx);
+  void *dw[4], *dsg[4], *dsel[9] = {nullptr}, *dz, *dg = nullptr, *dp = nullptr;
+  for (int k = 0; k < 4; ++k) { if ((rc = st.alloc(n * ELEM, &dw[k]))) return rc; if ((rc = st.alloc(n * 8, &dsg[k]))) return rc; }
+  for (int k = 0; k < 9; ++k) if (sel && sel[k]) { if ((rc = st.alloc(n * ELEM, &dsel[k]))) return rc; }
+  if ((rc = st.alloc((n + 1) * ELEM, &dz))) return rc;
+  if (gate_out && (rc = st.alloc(N * ELEM, &dg))) return rc;
+  if (perm_out && (rc = st.alloc(N * ELEM, &dp))) return rc;
+  R23Ws ws;
+  if ((rc = r23_workspace(ctx, n, N, (uint64_t*)dz, &ws))) return rc;
+  // the copy streams start behind whatever the context's stream has been given so far (use_host_stream has ordered
+  // that behind the context's earlier calls): the staging buffers may still be read by them
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_pipe[EV_PERM], s));
+  HIP_TRY(ctx, hipStreamWaitEvent(up, ctx->ev_pipe[EV_PERM], 0));
+  HIP_TRY(ctx, hipStreamWaitEvent(down, ctx->ev_pipe[EV_PERM], 0));
+
+  auto put = [&](void* dst, const void* host, size_t bytes) -> int {
+    if (bytes >= COPY_MIN && host_is_pageable(host)) {
+      HIP_TRY(ctx, hipStreamSynchronize(up));                 // the threaded copy uses streams of its own
+      return threaded_copy(ctx, dst, host, bytes, true);
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(dst, host, bytes, hipMemcpyHostToDevice, up));
+    return PLK_OK;
+  };
+  auto arrived = [&](int ev, hipStream_t waiter, hipStream_t waiter2 = nullptr) -> int {
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_pipe[ev], up));
+    HIP_TRY(ctx, hipStreamWaitEvent(waiter, ctx->ev_pipe[ev], 0));
+    if (waiter2) HIP_TRY(ctx, hipStreamWaitEvent(waiter2, ctx->ev_pipe[ev], 0));
+    return PLK_OK;
+  };
+  // page-locked destination: DMA on the download stream behind `ev`; pageable: wait for `ev`, then the threaded copy
+  auto get = [&](void* host, const void* src, size_t bytes, int ev, bool deferred) -> int {
+    const bool threaded = bytes >= COPY_MIN && host_is_pageable(host);
+    if (threaded != deferred) return PLK_OK;                  // each kind of destination is served in its own phase
+    if (threaded) {
+      HIP_TRY(ctx, hipEventSynchronize(ctx->ev_pipe[ev]));
+      return threaded_copy(ctx, host, src, bytes, false);
+    }
+    HIP_TRY(ctx, hipStreamWaitEvent(down, ctx->ev_pipe[ev], 0));
+    HIP_TRY(ctx, hipMemcpyAsync(host, src, bytes, hipMemcpyDeviceToHost, down));
+    return PLK_OK;
+  };
+
+  const uint64_t* w[4]; const uint64_t* sg[4]; const uint64_t* sl[9] = {nullptr};
+  for (int k = 0; k < 4; ++k) { w[k] = (const uint64_t*)dw[k]; sg[k] = (const uint64_t*)dsg[k]; }
+  for (int k = 0; k < 9; ++k) sl[k] = (const uint64_t*)dsel[k];
+
+  // 1. wires
+  for (int k = 0; k < 4; ++k) if ((rc = put(dw[k], wires[k], n * ELEM))) return rc;
+  if ((rc = arrived(EV_W, s, sa))) return rc;
+  {
+    const uint32_t kinds[4] = {NTT_IN_FIELD, NTT_IN_FIELD, NTT_IN_FIELD, NTT_IN_FIELD};
+    const int col_of[4] = {0, 1, 2, 3};
+    if ((rc = r23_extend_group(ctx, s, ws, w, kinds, col_of, 4))) return rc;
+  }
+  // 2. selectors, three at a time
+  {
+    const uint64_t* in[3]; uint32_t kinds[3]; int col_of[3]; size_t m = 0; int group = 0;
+    auto flush = [&]() -> int {
+      if (m == 0) return PLK_OK;
+      int r = arrived(EV_SEL0 + (group % 3), s);
+      if (r) return r;
+      ++group;
+      r = r23_extend_group(ctx, s, ws, in, kinds, col_of, m);
+      m = 0;
+      return r;
+    };
+    for (int k = 0; k < 9; ++k) {
+      if (!dsel[k]) continue;
+      if ((rc = put(dsel[k], sel[k], n * ELEM))) return rc;
+      in[m] = sl[k]; kinds[m] = NTT_IN_FIELD; col_of[m] = 4 + k; ++m;
+      if (m == 3 && (rc = flush())) return rc;
+    }
+    if ((rc = flush())) return rc;
+  }
+  // 3. gate constraints, and their vector on its way down at once
+  if (gate_out) {
+    if ((rc = r23_gate(ctx, s, ws, w, sl, (uint64_t*)dg))) return rc;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_pipe[EV_GATE], s));
+    if ((rc = get(gate_out, dg, N * ELEM, EV_GATE, false))) return rc;
+  }
+  // 4. sigma; the grand-product chain on the side stream, the sigma transforms on the main one
+  for (int k = 0; k < 4; ++k) if ((rc = put(dsg[k], sigma[k], n * 8))) return rc;
+  if ((rc = arrived(EV_S, s, sa))) return rc;
+  {
+    SideJoin side{ctx, s, sa};
+    if ((rc = r23_z_chain(ctx, sa, ws, w, sg, beta, gamma, ctx->ev_pipe[EV_Z]))) return rc;
+    side.record();
+    if (z_out && (rc = get(z_out, dz, (n + 1) * ELEM, EV_Z, false))) return rc;
+    const uint32_t kinds[4] = {NTT_IN_U64, NTT_IN_U64, NTT_IN_U64, NTT_IN_U64};
+    const int col_of[4] = {13, 14, 15, 16};
+    if ((rc = r23_extend_group(ctx, s, ws, sg, kinds, col_of, 4))) return rc;
+    side.join();
+  }
+  if (perm_out) {
+    if ((rc = r23_perm(ctx, s, ws, w, sg, beta, gamma, z_shift, (uint64_t*)dp))) return rc;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_pipe[EV_PERM], s));
+    if ((rc = get(perm_out, dp, N * ELEM, EV_PERM, false))) return rc;
+  }
+  // 5. pageable destinations: the calling thread copies them as their kernels finish
+  if (gate_out && (rc = get(gate_out, dg, N * ELEM, EV_GATE, true))) return rc;
+  if (z_out && (rc = get(z_out, dz, (n + 1) * ELEM, EV_Z, true))) return rc;
+  if (perm_out && (rc = get(perm_out, dp, N * ELEM, EV_PERM, true))) return rc;
+  // 6. deferred status (waits for the main stream), then the downloads still in flight
+  rc = fetch_status(ctx, s);
+  HIP_TRY(ctx, hipStreamSynchronize(down));
+  HIP_TRY(ctx, hipStreamSynchronize(up));
+  return rc;
+}
+
 // Prologue of every entry point that enqueues on a stream: use_device, then order the stream behind the
 // context's previous call if that went to another stream.
 int use_stream(plk_ctx* ctx, hipStream_t s) {
@@ -1404,6 +1569,9 @@ int plk_ctx_create(int device, plk_ctx** out) {
   CTX_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
   CTX_TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
   CTX_TRY(hipEventCreateWithFlags(&ctx->ev_order, hipEventDisableTiming));
+  CTX_TRY(hipStreamCreateWithFlags(&ctx->copy_up, hipStreamNonBlocking));
+  CTX_TRY(hipStreamCreateWithFlags(&ctx->copy_down, hipStreamNonBlocking));
+  for (auto& e : ctx->ev_pipe) CTX_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   CTX_TRY(hipMalloc((void**)&ctx->status_dev, sizeof(GpStatus)));
   CTX_TRY(hipHostMalloc((void**)&ctx->status_host, sizeof(GpStatus)));
   CTX_TRY(hipMemset(ctx->status_dev, 0xff, sizeof(GpStatus)));
@@ -1446,6 +1614,9 @@ void plk_ctx_destroy(plk_ctx* ctx) {
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->ev_order) (void)hipEventDestroy(ctx->ev_order);
+  for (auto& e : ctx->ev_pipe) if (e) (void)hipEventDestroy(e);
+  if (ctx->copy_up) (void)hipStreamDestroy(ctx->copy_up);
+  if (ctx->copy_down) (void)hipStreamDestroy(ctx->copy_down);
   if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -2121,7 +2292,10 @@ int plk_round23(plk_ctx* ctx, const uint64_t* const wires[4], const uint64_t* co
   if (rc) return rc;
   if ((rc = check_domain(ctx, n, &l1))) return rc;
   if ((rc = check_domain(ctx, N, &l2))) return rc;
-  if (!wires || !sigma) return fail(ctx, PLK_ERR_ARG, "null pointer");
+  if (!wires || !sigma || !beta || !gamma) return fail(ctx, PLK_ERR_ARG, "null pointer");
+  for (int k = 0; k < 4; ++k) if (!wires[k] || !sigma[k]) return fail(ctx, PLK_ERR_ARG, "null column pointer");
+  if (n <= N && r23_coset_form(n, N, l1))
+    return round23_host_pipelined(ctx, wires, sel, sigma, n, N, beta, gamma, z_shift, z_out, gate_out, perm_out);
   Staged st(ctx);
   const uint64_t* w[4]; const uint64_t* sg[4]; const uint64_t* s[9] = {nullptr};
   for (int k = 0; k < 4; ++k) {
