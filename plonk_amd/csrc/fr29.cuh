@@ -304,12 +304,18 @@ inline F9 f9_shoup_quotient_host(const Fe& w_canonical) {
 // below (0.4527 V_a V_b + 1) p  (p / 2^256 < 0.4527).
 __host__ __device__ __forceinline__ F9 mont256(const F9& a_in, const F9& b_in) {
   F9 a = a_in, b = b_in;
-#ifdef __HIP_DEVICE_COMPILE__
-  // The compiler must not know how many bits a limb has.  With freshly cut operands in registers (top limbs known
-  // to fit 24 bits, like m[8]) ROCm 7.2's clang for gfx950 produced a wrong top limb of the result; the same source
-  // is right on the host and when the operands come from memory, and the 24-bit multiply instructions it selects
-  // for such factors are right by themselves (tools/probe_mul24.hip).  The empty asm statements hide the ranges
-  // and emit nothing; tests/cpp/test_constraints_dev.hip watches over the result.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PLK_MONT256_NO_FENCE)   // (the macro: tools/probe_mont256.hip only)
+  // The compiler must not know how many bits a limb has.  Root cause of the wrong top limb seen without these
+  // fences (ROCm 7.2 clang, gfx950; tools/probe_mont256.hip reproduces it, 16322 of 16384 products wrong): m[8] is
+  // `x & 0xffffff` and p's top limb a 23-bit constant, so their product is first formed as a 24-bit multiply, whose
+  // operands' upper 8 bits are don't-care - which lets the combiner drop the `and`; that product is then folded with
+  // the neighbouring a[8] * b[8] pair (v_mul_u32_u24 + v_mul_hi_u32_u24, top limbs of freshly cut operands) into ONE
+  // full-width multiply-add,
+  //     v_mad_u64_u32 v[30:31], s[0:1], v51, s3, v[2:3]        ; v51 = 0 - acc, s3 = 0x73eda7
+  // which reads all 32 bits of the unmasked v51, while the masked copy (v_and_b32 v18, 0xffffff, v51) feeds the
+  // other products of m[8].  With the limb ranges hidden the same product is v_mad_u64_u32 of the masked register.
+  // mont29, mont29_x2 and shoup29_x2 mask to 29 bits and multiply by 29-bit limbs, so no 24-bit multiply is ever
+  // formed from a masked value there; tests/cpp/test_constraints_dev.hip checks them on freshly cut operands too.
 #pragma unroll
   for (int i = 0; i < 9; ++i) asm volatile("" : "+v"(a.l[i]), "+v"(b.l[i]));
 #endif
@@ -330,7 +336,7 @@ __host__ __device__ __forceinline__ F9 mont256(const F9& a_in, const F9& b_in) {
   for (int i = 0; i < 8; ++i) acc += (uint64_t)m[i] * f9c::kp_limb29(1, 8 - i);
   m[8] = (0u - (uint32_t)acc) & ((1u << 24) - 1);
   acc += m[8];                                   // the p[0] = 1 term: the low 24 bits are now zero
-#ifdef __HIP_DEVICE_COMPILE__
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PLK_MONT256_NO_FENCE)
   asm volatile("" : "+v"(m[8]));
 #endif
   c[0] = (uint32_t)acc & M29;

@@ -35,6 +35,16 @@ __global__ void check_kernel(int stage, int small, Fe beta, Fe gamma, Fe beta_r2
   if (stage == 3) { fe_store(out_want, i, lhs); fe_store(out_got, i, fe_reduce_f9(pt.lhs)); }
   if (stage == 4) { fe_store(out_want, i, rhs); fe_store(out_got, i, fe_reduce_f9(pt.rhs)); }
   if (stage == 5) { fe_store(out_want, i, fe_mul(z_next, lhs)); fe_store(out_got, i, fe_reduce_f9(mont256(pt.lhs, f9_from_fe(z_next)))); }
+  // the transforms' products on operands cut in registers just before (top limbs known to the compiler to fit 24
+  // bits, the situation in which mont256 needs its fences): mont29 returns a b 2^-261, i.e. fe_mul(a, b) / 32
+  if (stage == 6 || stage == 7) {
+    Fe r1, r2;
+    if (stage == 6) { r1 = fe_reduce_f9(mont29(f9_from_fe(w[0]), f9_from_fe(sg[0]))); r2 = r1; }
+    else { F9 o1, o2; mont29_x2(f9_from_fe(w[0]), f9_from_fe(sg[0]), f9_from_fe(w[1]), f9_from_fe(sg[1]), o1, o2); r1 = fe_reduce_f9(o1); r2 = fe_reduce_f9(o2); }
+    for (int d = 0; d < 5; ++d) { r1 = fe_double(r1); r2 = fe_double(r2); }
+    fe_store(out_want, i, stage == 6 ? fe_mul(w[0], sg[0]) : fe_add(fe_mul(w[0], sg[0]), fe_mul(w[1], sg[1])));
+    fe_store(out_got, i, stage == 6 ? r1 : fe_add(r1, r2));
+  }
 }
 
 int main() {
@@ -43,7 +53,7 @@ int main() {
   hipMalloc(&want, n * 32); hipMalloc(&got, n * 32);
   Fe R2; for (int i = 0; i < 8; ++i) R2.l[i] = Field::R2[i];
   int bad_total = 0;
-  for (int stage = 0; stage < 6; ++stage) for (int small = 0; small < 2; ++small) {
+  for (int stage = 0; stage < 8; ++stage) for (int small = 0; small < 2; ++small) {
     const Fe beta = small ? fe_from_u64(5) : fe_from_u64(0x123456789abcdefull), gamma = fe_from_u64(7);
     hipLaunchKernelGGL(check_kernel, dim3(n / 256), dim3(256), 0, 0, stage, small, beta, gamma, fe_mul(beta, R2), want, got, n);
     std::vector<uint64_t> a(n * 4), b(n * 4);
