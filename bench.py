@@ -133,11 +133,19 @@ def other_workloads(args, prover, dist, rank, world):
         dt = timed(lambda: pdist.four_step_ntt(x, N, prover), args.steps, args.warmup, dist, prover.device)
         ms = dt * 1e3 / args.steps
         gelem = N / (ms * 1e-3) / 1e9
+        # without the last exchange: the result stays as [my k1][k2] blocks (what an order-agnostic consumer takes)
+        ms_t = timed(lambda: pdist.four_step_ntt(x, N, prover, natural_output=False), args.steps, 1, dist, prover.device) * 1e3 / args.steps
+        direct_ms = None
+        if world == 1:
+            direct_ms = timed(lambda: prover.ntt_batch([x], N), args.steps, 1, dist, prover.device) * 1e3 / args.steps
         line = dict(base, metric=f"four-step NTT of 2^{args.log_n} points, natural order in and out", value=round(gelem, 3),
                     unit="Gelem/s", ms_per_step=round(ms, 4), higher_is_better=True, scaling="strong",
                     config={"workload": f"one transform of N=2^{args.log_n} sharded contiguously over {world} GPU(s), three "
                                         f"all-to-all exchanges of {(world - 1) * N // (world * world) * 32 / 2**20:.1f} MiB per GPU each"},
-                    frac_of_hbm_roofline=round(gelem / NTT_ROOFLINE_GELEM, 4))
+                    frac_of_hbm_roofline=round(gelem / NTT_ROOFLINE_GELEM, 4),
+                    transposed_output={"ms_per_step": round(ms_t, 4), "gelem_per_s": round(N / (ms_t * 1e-3) / 1e9, 3),
+                                       "note": "natural_output=False: two exchanges, result as [my k1][k2] = X[k1 + N1 k2]"},
+                    direct_transform_ms=round(direct_ms, 4) if direct_ms is not None else None)
     elif args.workload == "tables":
         # the two table-building steps before the path, from one flattened trace per GPU
         import torch

@@ -252,6 +252,27 @@ int plk_dev_extend4(plk_ctx* ctx, void* stream, const uint64_t* const* cols, con
 int plk_dev_ntt_strided(plk_ctx* ctx, void* stream, const uint64_t* in, size_t in_stride, uint32_t kind, size_t count,
                         size_t n_in, size_t N, int inverse, uint64_t* out, size_t out_stride);
 
+/* The two local phases of ONE transform of N points sharded over `ranks` GPUs (a power of two), rank `rank` holding the
+ * inputs [rank * N / ranks, (rank + 1) * N / ranks) (no counterpart in the reference: ark-poly runs one shared-memory
+ * FFT).  N = N1 * N2 with N1 = 2^ceil(log2(N) / 2), n = n1 * N2 + n2, k = k1 + N1 * k2, r1 = N1 / ranks, c2 = N2 / ranks.
+ * Both phases read the buffer exactly as an all-to-all delivers it and write exactly what the next all-to-all sends:
+ *   exchange 1 (caller): rank g sends its rows' columns [h c2, (h + 1) c2) to rank h; the receive buffer, blocks in
+ *       source order, IS the matrix [N1][c2] of this rank's columns;
+ *   plk_dev_fourstep_cols: the N1-point column transforms, the twiddles omega_N^(k1 n2) (and 1 / N if inverse) ->
+ *       send2_out = [k1][c2] with k1 in natural order, so destination h's block is rows [h r1, (h + 1) r1);
+ *   exchange 2 (caller): the receive buffer is [source h][k1 local][c2];
+ *   plk_dev_fourstep_rows: the N2-point row transforms on that buffer -> out, canonical values, either
+ *       natural_layout == 0: [k1 local][k2] = X[k1 + N1 k2] (N / ranks elements, no further exchange), or
+ *       natural_layout != 0: [h][k2 local][k1 local] with k2 = h c2 + k2 local, the send buffer of exchange 3, after
+ *       which rank h holds [source g][k2 local][k1 local]; k = k1 + N1 k2 with k1 = g r1 + k1 local, so one
+ *       transposition of the (g, k2 local) axes gives its contiguous range of X.
+ * Buffers hold N / ranks elements; input and output of a call must not alias.  PLK_ERR_ARG if `ranks` does not divide
+ * both N1 and N2 or leaves fewer than 2^floor(log2(N2) / 2) columns per rank (sizes above 2^7 per side). */
+int plk_dev_fourstep_cols(plk_ctx* ctx, void* stream, const uint64_t* recv1, size_t N, size_t ranks, size_t rank, int inverse,
+                          uint64_t* send2_out);
+int plk_dev_fourstep_rows(plk_ctx* ctx, void* stream, const uint64_t* recv2, size_t N, size_t ranks, size_t rank, int inverse,
+                          int natural_layout, uint64_t* out);
+
 /* out[i] = a[i] * b[i] (field product), n elements; out may alias a or b */
 int plk_dev_mul(plk_ctx* ctx, void* stream, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out);
 

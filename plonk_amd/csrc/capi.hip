@@ -140,6 +140,12 @@ struct plk_ctx {
   hipEvent_t ev_order = nullptr;
   std::map<std::pair<int, int>, NttPlan> plans;  // (log_n, inverse)
   DevBuf master_sh[2];                           // in-tile twiddle pairs for the precomputed-quotient product, per direction
+  struct FsPlan {                                // tables of one four-step transform seen from one rank (ntt.cuh, FsArgs)
+    int log_n = 0, log_n1 = 0, log_n2 = 0, la = 0, lb = 0, lA = 0, lB = 0, log_g = 0, lo_bits = 0;
+    DevBuf sub_a, sub_b, block, hi, lo;
+    const uint32_t *master = nullptr, *master_sh = nullptr;
+  };
+  std::map<std::array<long long, 4>, FsPlan> fs_plans;   // (log N, G, rank, inverse)
   std::map<std::string, DevBuf> ws;              // grow-only workspace slots
   struct PowTable { DevBuf lo, hi; size_t hi_count = 0; };
   std::map<std::array<uint64_t, 4>, PowTable> powers;   // g -> tables of g^j (coset transforms)
@@ -536,6 +542,140 @@ int launch_extend4(plk_ctx* ctx, hipStream_t s, const uint64_t* const* cols, con
                      (uint64_t)n);
   HIP_TRY(ctx, hipGetLastError());
   return PLK_OK;
+}
+
+// ---- four-step transform over G ranks: the two local phases (ntt.cuh, ntt_fs_kernel) ------------------------------
+
+// one sub-transform of 2^m points: a single pass up to 2^7 points (the tile then still holds 16 neighbouring
+// columns), two passes beyond
+void fs_digits(int m, int* hi, int* lo) {
+  if (m <= 7) { *hi = 0; *lo = 0; return; }
+  *hi = (m + 1) / 2; *lo = m - *hi;
+}
+
+int get_fs_plan(plk_ctx* ctx, hipStream_t s, int log_n, size_t G, size_t rank, bool inverse, plk_ctx::FsPlan** out) {
+  const std::array<long long, 4> key = {log_n, (long long)G, (long long)rank, inverse ? 1 : 0};
+  auto it = ctx->fs_plans.find(key);
+  if (it != ctx->fs_plans.end()) { *out = &it->second; return PLK_OK; }
+  const int log_g = log2_exact(G);
+  plk_ctx::FsPlan p;
+  p.log_n = log_n; p.log_n1 = (log_n + 1) / 2; p.log_n2 = log_n - p.log_n1; p.log_g = log_g;
+  if (log_g < 0 || rank >= G || log_g > p.log_n2) return fail(ctx, PLK_ERR_ARG, "ranks must be a power of two dividing both sides of the N1 x N2 view");
+  fs_digits(p.log_n1, &p.la, &p.lb);
+  fs_digits(p.log_n2, &p.lA, &p.lB);
+  const int log_c2 = p.log_n2 - log_g;
+  if (p.lB > log_c2) return fail(ctx, PLK_ERR_ARG, "too many ranks for this transform size");
+  struct Guard { plk_ctx::FsPlan* p; ~Guard() { if (p) for (DevBuf* b : {&p->sub_a, &p->sub_b, &p->block, &p->hi, &p->lo}) if (b->p) (void)hipFree(b->p); } } guard{&p};
+  NttPlan* small;
+  int rc;
+  if ((rc = get_plan(ctx, 4, inverse, s, &small))) return rc;   // any plan of this direction: the in-tile twiddle tables
+  p.master = small->tab.master; p.master_sh = small->tab.master_sh;
+  Fe w = root_of_unity(log_n);
+  if (inverse) w = fe_inverse(w);
+  const Fe one = fe_one();
+  auto sub_table = [&](DevBuf& buf, int m, int hi, int lo) -> int {
+    if (lo == 0) return PLK_OK;
+    Fe wm = w;
+    for (int i = 0; i < log_n - m; ++i) wm = fe_sqr(wm);
+    const uint64_t count = 1ull << m;
+    HIP_TRY(ctx, hipMalloc(&buf.p, count * TW_WORDS * 4));
+    buf.cap = count * TW_WORDS * 4;
+    hipLaunchKernelGGL(ntt_full_table_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, (uint32_t*)buf.p, hi, lo, wm, one);
+    HIP_TRY(ctx, hipGetLastError());
+    return PLK_OK;
+  };
+  if ((rc = sub_table(p.sub_a, p.log_n1, p.la, p.lb))) return rc;
+  if ((rc = sub_table(p.sub_b, p.log_n2, p.lA, p.lB))) return rc;
+  const Fe mul = inverse ? fe_inverse(fe_from_u64(1ull << log_n)) : one;
+  const uint64_t block_records = 1ull << (p.log_n1 + log_c2);
+  if (block_records <= (1ull << 24)) {
+    HIP_TRY(ctx, hipMalloc(&p.block.p, block_records * TW_WORDS * 4));
+    p.block.cap = block_records * TW_WORDS * 4;
+    hipLaunchKernelGGL(ntt_block_table_kernel, dim3((unsigned)((block_records + 255) / 256)), dim3(256), 0, s, (uint32_t*)p.block.p,
+                       1ull << p.log_n1, log_c2, (uint64_t)rank << log_c2, w, mul);
+    HIP_TRY(ctx, hipGetLastError());
+  } else {
+    p.lo_bits = log_n / 2;
+    if ((rc = alloc_table(ctx, p.lo, 1ull << p.lo_bits, w, 0, one, s))) return rc;
+    if ((rc = alloc_table(ctx, p.hi, 1ull << (log_n - p.lo_bits), w, p.lo_bits, mul, s))) return rc;
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  auto ins = ctx->fs_plans.emplace(key, p);
+  guard.p = nullptr;
+  *out = &ins.first->second;
+  return PLK_OK;
+}
+
+template <int MODE>
+int fs_launch(plk_ctx* ctx, hipStream_t s, const FsArgs& a, uint64_t tiles, const char* label, double elems, double per_elem) {
+  if (tiles == 0 || tiles > 0x7fffffffull) return fail(ctx, PLK_ERR_ARG, "four-step phase: bad grid");
+  ProfScope ps(ctx, s, label, 64.0 * elems, per_elem * elems);
+  hipLaunchKernelGGL(ntt_fs_kernel<MODE>, dim3((unsigned)tiles), dim3(NTT_THREADS), NTT_LDS_BYTES, s, a);
+  HIP_TRY(ctx, hipGetLastError());
+  return PLK_OK;
+}
+
+double fs_tile_products(int lr) { return lr < 2 ? 0.0 : 0.25 + (double)((lr - 2) / 2) + 0.5 * (double)((lr - 2) % 2); }
+
+FsArgs fs_args(const plk_ctx::FsPlan& p, size_t rank) {
+  FsArgs a{};
+  a.master = p.master; a.master_sh = p.master_sh;
+  a.tw_block = (const uint32_t*)p.block.p; a.tw_hi = (const uint32_t*)p.hi.p; a.tw_lo = (const uint32_t*)p.lo.p; a.lo_bits = p.lo_bits;
+  a.log_c2 = p.log_n2 - p.log_g; a.log_r1 = p.log_n1 - p.log_g; a.log_n2 = p.log_n2;
+  a.col0 = (uint64_t)rank << a.log_c2;
+  return a;
+}
+
+// phase A: recv1 = [N1][c2] -> send2 = [k1][c2]
+int launch_fs_cols(plk_ctx* ctx, hipStream_t s, const uint64_t* recv1, size_t N, size_t G, size_t rank, bool inverse, uint64_t* send2) {
+  int rc, log_n;
+  if ((rc = check_domain(ctx, N, &log_n))) return rc;
+  if (!recv1 || !send2 || recv1 == send2) return fail(ctx, PLK_ERR_ARG, "four-step phase: distinct non-null buffers expected");
+  plk_ctx::FsPlan* p;
+  if ((rc = get_fs_plan(ctx, s, log_n, G, rank, inverse, &p))) return rc;
+  FsArgs a = fs_args(*p, rank);
+  const double elems = (double)(N / G);
+  const uint64_t* src = recv1;
+  if (p->lb) {
+    void* tmp;
+    if ((rc = ws_get(ctx, "fs_tmp", (N / G) * ELEM, &tmp))) return rc;
+    a.in = src; a.out = (uint64_t*)tmp; a.tw_sub = (const uint32_t*)p->sub_a.p;
+    a.log_r = p->la; a.log_lo = p->lb; a.log_hi = 0; a.log_c = std::min(NTT_TILE_LOG - a.log_r, a.log_c2);
+    if ((rc = fs_launch<FS_A_FIRST>(ctx, s, a, (1ull << p->lb) << (a.log_c2 - a.log_c), "ntt_fs_kernel/cols/first", elems, fs_tile_products(a.log_r) + 1.0))) return rc;
+    src = (const uint64_t*)tmp;
+  }
+  a.in = src; a.out = send2; a.tw_sub = nullptr;
+  a.log_r = p->lb ? p->lb : p->log_n1; a.log_hi = p->lb ? p->la : 0; a.log_lo = 0; a.log_c = std::min(NTT_TILE_LOG - a.log_r, a.log_c2);
+  return fs_launch<FS_A_LAST>(ctx, s, a, (1ull << a.log_hi) << (a.log_c2 - a.log_c), "ntt_fs_kernel/cols/last", elems,
+                              fs_tile_products(a.log_r) + (p->block.p ? 1.0 : 2.0));
+}
+
+// phase B: recv2 = [G][r1][c2] -> out (natural: send3 = [G][c2][r1]; else transposed [r1][N2])
+int launch_fs_rows(plk_ctx* ctx, hipStream_t s, const uint64_t* recv2, size_t N, size_t G, size_t rank, bool inverse, bool natural, uint64_t* out) {
+  int rc, log_n;
+  if ((rc = check_domain(ctx, N, &log_n))) return rc;
+  if (!recv2 || !out || recv2 == out) return fail(ctx, PLK_ERR_ARG, "four-step phase: distinct non-null buffers expected");
+  plk_ctx::FsPlan* p;
+  if ((rc = get_fs_plan(ctx, s, log_n, G, rank, inverse, &p))) return rc;
+  FsArgs a = fs_args(*p, rank);
+  const double elems = (double)(N / G);
+  const uint64_t* src = recv2;
+  if (p->lB) {
+    void* tmp;
+    if ((rc = ws_get(ctx, "fs_tmp", (N / G) * ELEM, &tmp))) return rc;
+    a.in = src; a.out = (uint64_t*)tmp; a.tw_sub = (const uint32_t*)p->sub_b.p;
+    a.log_r = p->lA; a.log_lo = p->lB; a.log_hi = 0; a.log_c = std::min(NTT_TILE_LOG - a.log_r, p->lB);
+    if ((rc = fs_launch<FS_B_FIRST>(ctx, s, a, ((uint64_t)1 << a.log_r1) << (p->lB - a.log_c), "ntt_fs_kernel/rows/first", elems, fs_tile_products(a.log_r) + 1.0))) return rc;
+    src = (const uint64_t*)tmp;
+  }
+  a.in = src; a.out = out; a.tw_sub = nullptr;
+  a.log_r = p->lB ? p->lB : p->log_n2; a.log_hi = p->lB ? p->lA : 0; a.log_lo = 0;
+  if (natural) {
+    a.log_c = std::min(NTT_TILE_LOG - a.log_r, a.log_r1);
+    return fs_launch<FS_B_LAST_NATURAL>(ctx, s, a, (1ull << a.log_hi) << (a.log_r1 - a.log_c), "ntt_fs_kernel/rows/last", elems, fs_tile_products(a.log_r));
+  }
+  a.log_c = std::min(NTT_TILE_LOG - a.log_r, a.log_hi);
+  return fs_launch<FS_B_LAST_TRANSPOSED>(ctx, s, a, ((uint64_t)1 << a.log_r1) << (a.log_hi - a.log_c), "ntt_fs_kernel/rows/last", elems, fs_tile_products(a.log_r));
 }
 
 int status_reset(plk_ctx* ctx, hipStream_t s) {
@@ -1586,6 +1726,11 @@ int plk_ctx_create(int device, plk_ctx** out) {
   }
   CTX_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES));
   CTX_TRY(hipFuncSetAttribute((const void*)ntt_final_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES));
+  CTX_TRY(hipFuncSetAttribute((const void*)ntt_fs_kernel<FS_A_FIRST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES));
+  CTX_TRY(hipFuncSetAttribute((const void*)ntt_fs_kernel<FS_A_LAST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES));
+  CTX_TRY(hipFuncSetAttribute((const void*)ntt_fs_kernel<FS_B_FIRST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES));
+  CTX_TRY(hipFuncSetAttribute((const void*)ntt_fs_kernel<FS_B_LAST_NATURAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES));
+  CTX_TRY(hipFuncSetAttribute((const void*)ntt_fs_kernel<FS_B_LAST_TRANSPOSED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES));
 #undef CTX_TRY
   *out = ctx;
   return PLK_OK;
@@ -1598,6 +1743,7 @@ void plk_ctx_destroy(plk_ctx* ctx) {
   (void)hipDeviceSynchronize();
   for (auto& kv : ctx->plans) free_plan_tables(kv.second);
   for (auto& b : ctx->master_sh) if (b.p) (void)hipFree(b.p);
+  for (auto& kv : ctx->fs_plans) for (DevBuf* b : {&kv.second.sub_a, &kv.second.sub_b, &kv.second.block, &kv.second.hi, &kv.second.lo}) if (b->p) (void)hipFree(b->p);
   for (auto& kv : ctx->ws) if (kv.second.p) (void)hipFree(kv.second.p);
   msm_free_table(ctx);
   if (ctx->msm_sums) (void)hipHostFree(ctx->msm_sums);
@@ -1895,6 +2041,19 @@ int plk_dev_ntt_strided(plk_ctx* ctx, void* stream, const uint64_t* in, size_t i
     if ((rc = launch_ntt(ctx, (hipStream_t)stream, ins, kinds, m, n_in, N, inverse != 0, outs, in_stride, out_stride))) return rc;
   }
   return PLK_OK;
+}
+
+int plk_dev_fourstep_cols(plk_ctx* ctx, void* stream, const uint64_t* recv1, size_t N, size_t ranks, size_t rank, int inverse, uint64_t* send2_out) {
+  int rc = use_stream(ctx, (hipStream_t)stream);
+  if (rc) return rc;
+  return launch_fs_cols(ctx, (hipStream_t)stream, recv1, N, ranks, rank, inverse != 0, send2_out);
+}
+
+int plk_dev_fourstep_rows(plk_ctx* ctx, void* stream, const uint64_t* recv2, size_t N, size_t ranks, size_t rank, int inverse, int natural_layout,
+                          uint64_t* out) {
+  int rc = use_stream(ctx, (hipStream_t)stream);
+  if (rc) return rc;
+  return launch_fs_rows(ctx, (hipStream_t)stream, recv2, N, ranks, rank, inverse != 0, natural_layout != 0, out);
 }
 
 int plk_dev_mul(plk_ctx* ctx, void* stream, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {

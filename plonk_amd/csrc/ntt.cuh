@@ -381,6 +381,115 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void ntt_final_kernel(const NttFina
   else tile_transform<false>(tile, log_r, log_c, a.tab.master, a.tab.master_sh, quarter, load, store);
 }
 
+// ---- the local phases of a four-step transform sharded over G ranks ---------------------------------------------
+//
+// N = N1 * N2, n = n1 * N2 + n2, k = k1 + N1 * k2, rank g of G holds the contiguous inputs n1 in [g r1, (g + 1) r1),
+// r1 = N1 / G, and after the exchanges the columns n2 in [g c2, (g + 1) c2), c2 = N2 / G.  Both local phases run on
+// the buffers exactly as the all-to-all exchanges deliver them and write exactly what the next exchange sends, so no
+// pack or unpack copy stands between a collective and a kernel:
+//   phase A  (column transforms, size N1 = 2^(la + lb), n1 = a 2^lb + b):
+//     in   recv1 = [n1][c2]            (rank h's block of rows is what h sent: already row-major in n1)
+//     A_FIRST  digit a, times omega_N1^(k_a b)                     -> tmp  [k_a 2^lb + b][c2]
+//     A_LAST   digit b, times omega_N^(k1 (g c2 + col)) (and 1/N)  -> send2 [k1][c2], k1 = k_a + 2^la k_b
+//              (rows in k1 order: the rows of destination h are one contiguous block)
+//   phase B  (row transforms, size N2 = 2^(lA + lB), n2 = A 2^lB + B; recv2 = [h][k1l][c2], n2 = h c2 + j):
+//     B_FIRST  digit A, times omega_N2^(k_A B)                     -> tmp, same positions
+//     B_LAST   digit B -> canonical values, k2 = k_A + 2^lA k_B, written either
+//              transposed   [k1l][k2]                   (no further exchange), or
+//              send3 = [h][k2l][k1l], k2 = h c2 + k2l   (exchange 3 then delivers [g][k2l][k1l] to the owner of k2).
+// A sub-transform of at most 2^11 points is a single pass (the LAST kernel alone, lb = 0 or lB = 0).
+// The twiddle tables are records as everywhere else: tw_sub[(k << log_lo) + q] = omega_M^(k q),
+// tw_block[k1 * c2 + col] = omega_N^(k1 (col0 + col)) (times 1/N for the inverse), or the two-level pair if no block.
+enum FsMode : int { FS_A_FIRST = 0, FS_A_LAST = 1, FS_B_FIRST = 2, FS_B_LAST_NATURAL = 3, FS_B_LAST_TRANSPOSED = 4 };
+
+struct FsArgs {
+  const uint64_t* in;
+  uint64_t* out;
+  const uint32_t* master;
+  const uint32_t* master_sh;
+  const uint32_t* tw_sub;     // FIRST modes
+  const uint32_t* tw_block;   // A_LAST: full block, or nullptr
+  const uint32_t* tw_hi;      // A_LAST without a block: omega_N^(e << lo_bits) (times 1/N for the inverse) ...
+  const uint32_t* tw_lo;      // ... and omega_N^e
+  int lo_bits;
+  int log_r;       // this pass's radix
+  int log_lo;      // bits of the lower digit of the sub-transform (lb / lB; 0 for a single pass)
+  int log_hi;      // bits of the higher digit (la / lA; 0 for a single pass)
+  int log_c;       // columns per tile
+  int log_c2;      // log2(N2 / G)
+  int log_r1;      // log2(N1 / G)
+  int log_n2;      // log2(N2)
+  uint64_t col0;   // rank * c2
+};
+
+template <int MODE>
+__global__ __launch_bounds__(NTT_THREADS, 4) void ntt_fs_kernel(const FsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const Tile tile(lds_raw);
+  const int log_r = a.log_r, log_c = a.log_c, log_c2 = a.log_c2;
+  const uint64_t* __restrict__ in = a.in;
+  uint64_t* __restrict__ out = a.out;
+  const uint64_t cmask2 = (1ull << log_c2) - 1;
+  // phase B address of (k1l, n2) in recv2 = [h][k1l][c2]
+  auto addr_b = [&](uint64_t k1l, uint64_t n2) { return ((n2 >> log_c2) << (a.log_r1 + log_c2)) + (k1l << log_c2) + (n2 & cmask2); };
+  const uint32_t wg = blockIdx.x;
+  auto run = [&](auto load, auto store) {
+    if (a.master_sh && log_r >= 3 && log_r <= NTT_LDS_TW_LOG) tile_transform<true>(tile, log_r, log_c, a.master, a.master_sh, false, load, store);
+    else tile_transform<false>(tile, log_r, log_c, a.master, a.master_sh, false, load, store);
+  };
+  if constexpr (MODE == FS_A_FIRST) {
+    const uint64_t colblocks = 1ull << (log_c2 - log_c);
+    const uint64_t b = wg / colblocks, colbase = (wg % colblocks) << log_c;
+    run([&](int r, int c) { return f9_from_fe(fe_load(in, (((((uint64_t)r << a.log_lo) + b)) << log_c2) + colbase + c)); },
+        [&](int k, int c, const F9& v) {
+          const F9 tw = f9_load_tw(a.tw_sub, ((uint64_t)k << a.log_lo) + b);
+          fe_store(out, ((((uint64_t)k << a.log_lo) + b) << log_c2) + colbase + c, fe_pack_f9(mont29(v, tw)));
+        });
+  } else if constexpr (MODE == FS_A_LAST) {
+    const uint64_t colblocks = 1ull << (log_c2 - log_c);
+    const uint64_t ka = wg / colblocks, colbase = (wg % colblocks) << log_c;
+    run([&](int r, int c) { return f9_from_fe(fe_load(in, (((ka << log_r) + (uint64_t)r) << log_c2) + colbase + c)); },
+        [&](int k, int c, const F9& v) {
+          const uint64_t k1 = ka + ((uint64_t)k << a.log_hi), col = colbase + c;
+          const F9 tw = a.tw_block ? f9_load_tw(a.tw_block, (k1 << log_c2) + col)
+                                   : twiddle_two_level(a.tw_hi, a.tw_lo, a.lo_bits, k1 * (a.col0 + col));
+          fe_store(out, (k1 << log_c2) + col, fe_pack_f9(mont29(v, tw)));
+        });
+  } else if constexpr (MODE == FS_B_FIRST) {
+    const uint64_t bblocks = 1ull << (a.log_lo - log_c);
+    const uint64_t k1l = wg / bblocks, b0 = (wg % bblocks) << log_c;
+    run([&](int r, int c) { return f9_from_fe(fe_load(in, addr_b(k1l, ((uint64_t)r << a.log_lo) + b0 + c))); },
+        [&](int k, int c, const F9& v) {
+          const F9 tw = f9_load_tw(a.tw_sub, ((uint64_t)k << a.log_lo) + b0 + c);
+          fe_store(out, addr_b(k1l, ((uint64_t)k << a.log_lo) + b0 + c), fe_pack_f9(mont29(v, tw)));
+        });
+  } else if constexpr (MODE == FS_B_LAST_NATURAL) {   // columns = neighbouring k1l
+    const uint64_t kblocks = 1ull << (a.log_r1 - log_c);
+    const uint64_t kA = wg / kblocks, k1l0 = (wg % kblocks) << log_c;
+    run([&](int r, int c) { return f9_from_fe(fe_load(in, addr_b(k1l0 + c, (kA << log_r) + (uint64_t)r))); },
+        [&](int k, int c, const F9& v) {
+          const uint64_t k2 = kA + ((uint64_t)k << a.log_hi);
+          fe_store(out, ((k2 >> log_c2) << (log_c2 + a.log_r1)) + ((k2 & cmask2) << a.log_r1) + k1l0 + c, fe_reduce_f9(v));
+        });
+  } else {                  // FS_B_LAST_TRANSPOSED, columns = neighbouring k_A
+    const uint64_t ablocks = 1ull << (a.log_hi - log_c);
+    const uint64_t k1l = wg / ablocks, kA0 = (wg % ablocks) << log_c;
+    run([&](int r, int c) { return f9_from_fe(fe_load(in, addr_b(k1l, ((kA0 + c) << log_r) + (uint64_t)r))); },
+        [&](int k, int c, const F9& v) {
+          const uint64_t k2 = kA0 + c + ((uint64_t)k << a.log_hi);
+          fe_store(out, (k1l << a.log_n2) + k2, fe_reduce_f9(v));
+        });
+  }
+}
+
+// record[k1 * c2 + col] = base^(k1 (col0 + col)) * mul, k1 < rows, col < 2^log_c2
+__global__ void ntt_block_table_kernel(uint32_t* out, uint64_t rows, int log_c2, uint64_t col0, Fe base, Fe mul) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (rows << log_c2)) return;
+  const uint64_t k1 = i >> log_c2, col = i & ((1ull << log_c2) - 1);
+  f9_store_tw(out, i, f9_twiddle_from_fe(fe_mul(fe_pow_u64(base, k1 * (col0 + col)), mul)));
+}
+
 // ---- table construction (device side, run once per plan)
 
 // record[i] = (base^(i << shift) * mul) as a twiddle record, i < count; base, mul in the

@@ -263,6 +263,19 @@ class DeviceProver:
                                                     length, N, 1 if inverse else 0, _ptr(out), N))
         return out
 
+    def fourstep_cols(self, recv1: torch.Tensor, N: int, ranks: int, rank: int, inverse: bool = False) -> torch.Tensor:
+        """Phase A of a sharded transform on the buffer exchange 1 delivered; returns the send buffer of exchange 2."""
+        out = torch.empty_like(recv1)
+        self.ctx.check(self.lib.plk_dev_fourstep_cols(self.ctx.handle, self._stream(), _ptr(recv1), N, ranks, rank, 1 if inverse else 0, _ptr(out)))
+        return out
+
+    def fourstep_rows(self, recv2: torch.Tensor, N: int, ranks: int, rank: int, inverse: bool = False, natural_layout: bool = True) -> torch.Tensor:
+        """Phase B on the buffer exchange 2 delivered; returns the send buffer of exchange 3, or the transposed block."""
+        out = torch.empty_like(recv2)
+        self.ctx.check(self.lib.plk_dev_fourstep_rows(self.ctx.handle, self._stream(), _ptr(recv2), N, ranks, rank, 1 if inverse else 0,
+                                                      1 if natural_layout else 0, _ptr(out)))
+        return out
+
     def mul(self, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
         out = torch.empty_like(a)
         self.ctx.check(self.lib.plk_dev_mul(self.ctx.handle, self._stream(), _ptr(a), _ptr(b), a.numel() // 4, _ptr(out)))

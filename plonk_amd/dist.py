@@ -1,6 +1,14 @@
 """Multi-GPU forms of the hot path: one process per GPU, torch.distributed (RCCL on GPUs, gloo on
 CPU for the tests) for the exchanges, libplonk_hip.so for every local computation.
 
+Stream protocol: the library enqueues every kernel on torch's CURRENT stream (plonk_amd.device passes
+`torch.cuda.current_stream()` to each plk_dev_* call; side streams the library uses internally are joined back into
+it before the call returns).  torch.distributed's RCCL process group runs a collective on a stream of its own, which
+it orders behind the current stream when the collective is issued, and - for the blocking form used here - makes the
+current stream wait for before the call returns.  So a kernel, the collective that sends its output and the kernel
+that consumes the received buffer run in issue order with no host synchronisation, and the caching allocator is told
+of the second stream by the process group itself.  Any other backend is handed host copies (`_staged`).
+
 Three ways the path shards (the reference has no distribution of any kind):
 
 * `shard_circuits`  - batched proofs: whole circuits round-robin over ranks, no collective.
@@ -20,8 +28,14 @@ from __future__ import annotations
 
 from typing import List, Optional, Sequence
 
+import os
+
 import torch
 import torch.distributed as dist
+
+#: PLONK_DIST_FORCE_COLLECTIVES=1 issues the collectives even in a one-rank group, where they move nothing: a way
+#: to run RCCL itself, and its ordering against the library's kernels, on a machine with a single GPU
+_FORCE = os.environ.get("PLONK_DIST_FORCE_COLLECTIVES") == "1"
 
 
 def _world(group=None):
@@ -41,7 +55,7 @@ def _staged(t: torch.Tensor, group=None) -> bool:
 def _all_to_all(send: torch.Tensor, group=None) -> torch.Tensor:
     """send[h] goes to rank h; returns recv with recv[g] = what rank g sent to us."""
     _, world = _world(group)
-    if world == 1:
+    if world == 1 and not (_FORCE and dist.is_initialized()):
         return send
     if _staged(send, group):
         host = send.contiguous().cpu()
@@ -86,7 +100,12 @@ def four_step_ntt(x_local: torch.Tensor, N: int, engine, group=None, inverse: bo
     """Transform of size N whose input is sharded contiguously by index: this rank passes
     elements [rank * N/G, (rank + 1) * N/G).  Returns the same range of the result
     (natural_output=True) or, saving the last exchange, the block [k1 in my rows][all k2] holding
-    X[k1 + N1 * k2] as an `(N1/G, N2, 4)` tensor."""
+    X[k1 + N1 * k2] as an `(N1/G, N2, 4)` tensor.
+
+    With an engine that has the fused phases (`fourstep_cols` / `fourstep_rows`, the HIP library) the local kernels
+    read what an exchange delivered and write what the next one sends: the only copies left are the pack of the
+    caller's contiguous input before exchange 1 and, for natural order, the transposition after exchange 3.
+    Bytes per exchange and rank: (G - 1) / G of its N / G elements, 32 bytes each, one message per peer."""
     rank, G = _world(group)
     N1, N2 = split_domain(N)
     if N1 % G or N2 % G:
@@ -94,6 +113,43 @@ def four_step_ntt(x_local: torch.Tensor, N: int, engine, group=None, inverse: bo
     r1, c2 = N1 // G, N2 // G
     if x_local.shape != (N // G, 4):
         raise ValueError(f"expected a ({N // G}, 4) shard, got {tuple(x_local.shape)}")
+    if not _fused_four_step_ok(engine, N1, N2, G):
+        return _four_step_ntt_unfused(x_local, N, engine, group, inverse, natural_output)
+
+    # exchange 1: my rows, everyone's columns  ->  everyone's rows, my columns.  The receive buffer, blocks in source
+    # order, is the row-major matrix [n1][my c2 columns].
+    send = x_local.view(r1, G, c2, 4).permute(1, 0, 2, 3).contiguous() if G > 1 else x_local
+    recv = _all_to_all(send, group)
+    send2 = engine.fourstep_cols(recv.view(N // G, 4), N, G, rank, inverse=inverse)        # [k1][c2], twiddled
+    # exchange 2: destination h's rows k1 in [h r1, (h + 1) r1) are one contiguous block
+    recv2 = _all_to_all(send2.view(G, r1 * c2, 4), group)                                 # [source][k1 local][c2]
+    out = engine.fourstep_rows(recv2.view(N // G, 4), N, G, rank, inverse=inverse, natural_layout=natural_output)
+    if not natural_output:
+        return out.view(r1, N2, 4)                                                         # [my k1][k2] = X[k1 + N1 k2]
+    # exchange 3: [destination h][k2 local][k1 local] -> [source g][k2 local][k1 local]; k = (g r1 + k1 local) + N1 k2
+    recv3 = _all_to_all(out.view(G, c2 * r1, 4), group)
+    if G == 1:
+        return recv3.view(N // G, 4)
+    return recv3.view(G, c2, r1, 4).permute(1, 0, 2, 3).contiguous().view(N // G, 4)
+
+
+def _fused_four_step_ok(engine, N1: int, N2: int, G: int) -> bool:
+    """The library's fused phases need a power-of-two number of ranks and, for sides above 2^7, at least
+    2^floor(log2(N2) / 2) columns per rank (plk_dev_fourstep_cols in plonk_hip.h)."""
+    if not (hasattr(engine, "fourstep_cols") and hasattr(engine, "fourstep_rows")) or G & (G - 1):
+        return False
+    m2 = N2.bit_length() - 1
+    low = 0 if m2 <= 7 else m2 - (m2 + 1) // 2
+    return (N2 // G) >= (1 << low) and N1 >= 4 and N2 >= 4
+
+
+def _four_step_ntt_unfused(x_local: torch.Tensor, N: int, engine, group=None, inverse: bool = False,
+                           natural_output: bool = True) -> torch.Tensor:
+    """The same transform from generic pieces (independent row transforms, an element-wise product, torch copies for
+    every change of layout): what an engine without the fused phases runs, e.g. the CPU oracle engine of the tests."""
+    rank, G = _world(group)
+    N1, N2 = split_domain(N)
+    r1, c2 = N1 // G, N2 // G
 
     # exchange 1: my rows, everyone's columns  ->  everyone's rows, my columns
     send = x_local.view(r1, G, c2, 4).permute(1, 0, 2, 3).contiguous()

@@ -80,6 +80,35 @@ def test_ranks_share_the_gpu(world):
     assert r.stdout.count(" ok") == world
 
 
+def test_rccl_runs_in_a_one_rank_group():
+    """RCCL itself (backend "nccl"), which needs one GPU per rank, in a group of one rank with the collectives forced:
+    all-to-all, all-gather, all-reduce and barrier between the library's kernels on device tensors."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "dist_rccl_worker.py")], env=dict(os.environ, OMP_NUM_THREADS="4"),
+                       capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "rccl one-rank ok" in r.stdout
+
+
+def test_four_step_fused_phases_all_layouts(prover):
+    """The fused phases at world size 1 for sizes on both sides of the single-pass / two-pass boundary (a side above
+    2^7 points takes two passes), both directions and both output layouts, against the direct transform."""
+    for log_n in (4, 7, 14, 15, 16, 19, 22):
+        N = 1 << log_n
+        x = to_device(synth.random_elements(500 + log_n, N), prover.device)
+        direct = prover.ntt_batch([x], N)[0]
+        assert torch.equal(pdist.four_step_ntt(x, N, prover), direct), log_n
+        N1, N2 = pdist.split_domain(N)
+        blk = pdist.four_step_ntt(x, N, prover, natural_output=False)
+        assert torch.equal(blk, direct.view(N2, N1, 4).permute(1, 0, 2)), log_n
+        assert torch.equal(pdist.four_step_ntt(direct, N, prover, inverse=True), x), log_n
+        if log_n <= 16:
+            assert np.array_equal(to_host(direct), co.ntt(to_host(x), N)), log_n
+
+
 @pytest.mark.parametrize("n,ranges", [(1 << 14, 4), (5000, 3), (1025, 2), (7, 7)])
 def test_grand_product_by_row_ranges(prover, n, ranges):
     """plk_dev_grand_product_local / _finish on one GPU, range after range, against the serial recurrence."""
