@@ -770,7 +770,10 @@ int launch_grand_product(plk_ctx* ctx, hipStream_t s, const uint64_t* const wire
     cols.v[k] = wires[k];
     cols.sigma[k] = sigma[k];
   }
-  const size_t nb = (n + GP_BLOCK_ROWS - 1) / GP_BLOCK_ROWS;
+  // small circuits: one row per thread, a block's latency being what the call waits for (grand_product.cuh)
+  const bool small = n <= GP_SMALL_ROWS;
+  const size_t block_rows = small ? (size_t)GP_THREADS : (size_t)GP_BLOCK_ROWS;
+  const size_t nb = (n + block_rows - 1) / block_rows;
   if (nb > 0xffffffffull) return fail(ctx, PLK_ERR_ARG, "too many rows");
   uint64_t* ratio = fixed;
   if (!ratio) {
@@ -782,8 +785,12 @@ int launch_grand_product(plk_ctx* ctx, hipStream_t s, const uint64_t* const wire
   const Fe beta_r2 = fe_mul(beta, fe_r2());
   {
     ProfScope ps(ctx, s, "gp_local_z_kernel", 320.0 * (double)n, 24.0 * (double)n);   // 4 values + 4 indices + 4 gathers in, z out
-    hipLaunchKernelGGL(gp_local_z_kernel, dim3((unsigned)nb), dim3(GP_THREADS), 0, s, cols, (uint64_t)n, beta, gamma, beta_r2,
-                       z_out + 4, z_out, ratio, ctx->status_dev);
+    if (small)
+      hipLaunchKernelGGL(gp_local_z_small_kernel, dim3((unsigned)nb), dim3(GP_THREADS), 0, s, cols, (uint64_t)n, beta, gamma, beta_r2,
+                         z_out + 4, z_out, ratio, ctx->status_dev);
+    else
+      hipLaunchKernelGGL(gp_local_z_kernel, dim3((unsigned)nb), dim3(GP_THREADS), 0, s, cols, (uint64_t)n, beta, gamma, beta_r2,
+                         z_out + 4, z_out, ratio, ctx->status_dev);
   }
   HIP_TRY(ctx, hipGetLastError());
   if (nb > 1) {
@@ -794,7 +801,8 @@ int launch_grand_product(plk_ctx* ctx, hipStream_t s, const uint64_t* const wire
     HIP_TRY(ctx, hipGetLastError());
     {
       ProfScope ps(ctx, s, "gp_apply_kernel", 0.0, (double)n);
-      hipLaunchKernelGGL(gp_apply_kernel, dim3((unsigned)(nb - 1)), dim3(GP_THREADS), 0, s, z_out + 4, (uint64_t)n, (const uint64_t*)ratio);
+      if (small) hipLaunchKernelGGL(gp_apply_kernel<1>, dim3((unsigned)(nb - 1)), dim3(GP_THREADS), 0, s, z_out + 4, (uint64_t)n, (const uint64_t*)ratio);
+      else hipLaunchKernelGGL(gp_apply_kernel<GP_ITEMS>, dim3((unsigned)(nb - 1)), dim3(GP_THREADS), 0, s, z_out + 4, (uint64_t)n, (const uint64_t*)ratio);
     }
     HIP_TRY(ctx, hipGetLastError());
   }
@@ -1722,7 +1730,9 @@ int plk_ctx_create(int device, plk_ctx** out) {
     hipFuncAttributes fa;
     CTX_TRY(hipFuncGetAttributes(&fa, (const void*)gp_local_z_kernel));
     CTX_TRY(hipFuncGetAttributes(&fa, (const void*)gp_ratio_scan_kernel));
-    CTX_TRY(hipFuncGetAttributes(&fa, (const void*)gp_apply_kernel));
+    CTX_TRY(hipFuncGetAttributes(&fa, (const void*)gp_apply_kernel<GP_ITEMS>));
+    CTX_TRY(hipFuncGetAttributes(&fa, (const void*)gp_apply_kernel<1>));
+    CTX_TRY(hipFuncGetAttributes(&fa, (const void*)gp_local_z_small_kernel));
   }
   CTX_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES));
   CTX_TRY(hipFuncSetAttribute((const void*)ntt_final_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES));

@@ -20,6 +20,7 @@ constexpr int GP_THREADS = 256;
 constexpr int GP_ITEMS = 4;
 constexpr int GP_BLOCK_ROWS = GP_THREADS * GP_ITEMS;
 constexpr int GP_SCAN_THREADS = 1024;
+constexpr int GP_SMALL_ROWS = 1 << 15;        // up to here: one row per thread (gp_local_z_small_kernel)
 
 struct GpStatus {
   unsigned long long zero_den_row;   // ~0ull = none
@@ -149,6 +150,32 @@ __global__ __launch_bounds__(GP_THREADS, 4) void gp_local_z_kernel(GpCols cols, 
   if (z0 && blockIdx.x == 0 && threadIdx.x == 0) fe_store(z0, 0, fe_one());
 }
 
+// Kernel A for small circuits: ONE row per thread (blocks of GP_THREADS rows).  A block's latency is what a small
+// circuit waits for - its rows' terms, the two scans, the inversion, the finish, all dependent - and with one row
+// per thread the terms and the finish are a quarter as long; the price, one inversion per 256 rows instead of per
+// 1024, is paid in parallel while the GPU has lanes to spare.
+__global__ __launch_bounds__(GP_THREADS) void gp_local_z_small_kernel(GpCols cols, uint64_t n, Fe beta, Fe gamma, Fe beta_r2,
+                                                                      uint64_t* z_after, uint64_t* z0, uint64_t* ratio, GpStatus* status) {
+  __shared__ Fe lds[GP_THREADS / 64];
+  __shared__ Fe edge[GP_THREADS / 64];
+  __shared__ Fe inv_total;
+  const uint64_t j = (uint64_t)blockIdx.x * GP_THREADS + threadIdx.x;
+  Fe nj, dj;
+  gp_row_terms(cols, n, j, beta, gamma, beta_r2, status, nj, dj);
+  Fe tot_n, tot_d;
+  const Fe inc_d = block_scan_mul<GP_THREADS, true>(dj, lds, &tot_d);      // denominators first: the inversion can start
+  if (threadIdx.x == GP_THREADS - 1) inv_total = fe_inverse_gcd32(tot_d);  // (the last wave idles in the next scan's tail)
+  const Fe inc_n = block_scan_mul<GP_THREADS, false>(nj, lds, &tot_n);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  Fe ex_d = fe_shfl(inc_d, (lane + 1) & 63);
+  if (lane == 0) edge[wave] = inc_d;
+  __syncthreads();
+  if (lane == 63) ex_d = wave == GP_THREADS / 64 - 1 ? fe_one() : edge[wave + 1];
+  if (threadIdx.x == 0) fe_store(ratio, blockIdx.x, fe_mul(tot_n, inv_total));
+  if (j < n) fe_store(z_after, j, fe_mul(inc_n, fe_mul(ex_d, inv_total)));     // prefix of numerators * suffix of denominators / all denominators
+  if (z0 && blockIdx.x == 0 && threadIdx.x == 0) fe_store(z0, 0, fe_one());
+}
+
 // Kernel B (one workgroup): exclusive prefix products of the nb block ratios, in place.
 __global__ __launch_bounds__(GP_SCAN_THREADS) void gp_ratio_scan_kernel(uint64_t* ratio, uint32_t nb) {
   __shared__ Fe lds[GP_SCAN_THREADS / 64];
@@ -168,12 +195,13 @@ __global__ __launch_bounds__(GP_SCAN_THREADS) void gp_ratio_scan_kernel(uint64_t
 }
 
 // Kernel C: z_after[j] *= carry[block of j]; block 0's carry is one and its rows are left alone.
+template <int ITEMS>
 __global__ __launch_bounds__(GP_THREADS) void gp_apply_kernel(uint64_t* z_after, uint64_t n, const uint64_t* carry) {
   const uint32_t b = blockIdx.x + 1;
   const Fe c = fe_load(carry, b);
-  const uint64_t base = (uint64_t)b * GP_BLOCK_ROWS;
+  const uint64_t base = (uint64_t)b * GP_THREADS * ITEMS;
 #pragma unroll
-  for (int it = 0; it < GP_ITEMS; ++it) {
+  for (int it = 0; it < ITEMS; ++it) {
     const uint64_t j = base + (uint64_t)it * GP_THREADS + threadIdx.x;     // consecutive threads, consecutive rows
     if (j < n) fe_store(z_after, j, fe_mul(fe_load(z_after, j), c));
   }
