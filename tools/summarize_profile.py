@@ -22,9 +22,9 @@ from collections import OrderedDict, defaultdict
 # (side-stream transforms carry 1 column, main-stream ones 17; an extension has 3 cosets per column)
 # and, for the two passes of one transform, by their order within that (name, grid) class.
 BY_GRID = {
-    "gp_terms_kernel": [["gp_terms_kernel"]],
-    "gp_block_scan_kernel": [["gp_block_scan_kernel"]],
-    "gp_finish_kernel": [["gp_finish_kernel"]],
+    "gp_local_z_kernel": [["gp_local_z_kernel"]],
+    "gp_ratio_scan_kernel": [["gp_ratio_scan_kernel"]],
+    "gp_apply_kernel": [["gp_apply_kernel"]],
     "ntt_pass_kernel": [["ntt_pass_kernel/intt20/side/p0", "ntt_pass_kernel/intt20/side/p1"],
                         ["ntt_pass_kernel/lde20to22/side/p0", "ntt_pass_kernel/lde20to22/side/p1"],
                         ["ntt_pass_kernel/intt20/p0", "ntt_pass_kernel/intt20/p1"],
@@ -38,7 +38,11 @@ STEP = [l for groups in BY_GRID.values() for g in groups for l in g]
 
 
 def short(name):
-    return name.split("(")[0].replace("plk::", "")
+    """'void plk::gp_apply_kernel<4>(unsigned long*, ...)' -> 'gp_apply_kernel'"""
+    base = name.split("(")[0].replace("plk::", "")
+    if base.startswith("void "):
+        base = base[5:]
+    return base.split("<")[0]
 
 
 def grid_of(r):
@@ -49,7 +53,7 @@ def grid_of(r):
 
 def labelled(rows, name_key):
     """yield (label, row) for the dispatches that belong to round-2+3 steps."""
-    rows = [r for r in rows if r[name_key].startswith("plk::") and "table_kernel" not in r[name_key]]
+    rows = [r for r in rows if "plk::" in r[name_key].split("(")[0] and "table_kernel" not in r[name_key]]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     grids = defaultdict(set)
     for r in rows:
