@@ -782,14 +782,29 @@ int launch_grand_product(plk_ctx* ctx, hipStream_t s, const uint64_t* const wire
     if (rc) return rc;
     ratio = (uint64_t*)p;
   }
-  const Fe beta_r2 = fe_mul(beta, fe_r2());
+  // per-call constants of the kernel's radix-2^261 arithmetic (grand_product.cuh, GpConsts)
+  GpConsts k9;
+  {
+    Fe t = beta;                                      // beta R
+    for (int i = 0; i < 10; ++i) t = fe_double(t);    // beta 2^266
+    k9.beta_sigma = f9_from_fe(t);
+    Fe c = fe_r2();                                   // 2^512
+    for (int i = 0; i < 10; ++i) c = fe_double(c);    // 2^522
+    k9.beta_index = f9_from_fe(fe_mul(beta, c));      // beta 2^256 2^522 / 2^256
+    t = gamma;
+    for (int i = 0; i < 5; ++i) t = fe_double(t);     // gamma 32 R
+    k9.gamma = f9_from_fe(t);
+    t = fe_one();
+    for (int i = 0; i < 5; ++i) t = fe_double(t);
+    k9.one = f9_from_fe(t);
+  }
   {
     ProfScope ps(ctx, s, "gp_local_z_kernel", 320.0 * (double)n, 24.0 * (double)n);   // 4 values + 4 indices + 4 gathers in, z out
     if (small)
-      hipLaunchKernelGGL(gp_local_z_small_kernel, dim3((unsigned)nb), dim3(GP_THREADS), 0, s, cols, (uint64_t)n, beta, gamma, beta_r2,
+      hipLaunchKernelGGL(gp_local_z_small_kernel, dim3((unsigned)nb), dim3(GP_THREADS), 0, s, cols, (uint64_t)n, k9,
                          z_out + 4, z_out, ratio, ctx->status_dev);
     else
-      hipLaunchKernelGGL(gp_local_z_kernel, dim3((unsigned)nb), dim3(GP_THREADS), 0, s, cols, (uint64_t)n, beta, gamma, beta_r2,
+      hipLaunchKernelGGL(gp_local_z_kernel, dim3((unsigned)nb), dim3(GP_THREADS), 0, s, cols, (uint64_t)n, k9,
                          z_out + 4, z_out, ratio, ctx->status_dev);
   }
   HIP_TRY(ctx, hipGetLastError());

@@ -13,6 +13,7 @@
 // panic (:235-238); both are recorded in `GpStatus` (smallest offending row).
 #pragma once
 #include "field.cuh"
+#include "fr29.cuh"
 
 namespace plk {
 
@@ -86,67 +87,145 @@ __device__ __forceinline__ Fe block_scan_mul(Fe v, Fe* lds, Fe* total) {
 // for the carry - against 288 + 64 out, 64 + 32 back in of the three-kernel form below (kept for row ranges on
 // several GPUs, which need the products apart) - and no single-workgroup inversion on the critical path.
 
-// num_j and den_j of one row (one for a row beyond the circuit), failures recorded with their row
-__device__ __forceinline__ void gp_row_terms(const GpCols& cols, uint64_t n, uint64_t j, const Fe& beta, const Fe& gamma, const Fe& beta_r2,
-                                             GpStatus* status, Fe& nj, Fe& dj) {
-  nj = fe_one(); dj = fe_one();
+// The first kernel's arithmetic runs on 29-bit limbs with the transforms' product mont29 (a b 2^-261, fr29.cuh):
+// ~195 vector instructions per product against ~390 for fe_mul, and its result is below (V_a V_b / 70.7 + 1) p, so
+// chains of products stay small with no reduction in between.  For that the values live in the Montgomery form of
+// radix R' = 2^261 = 32 R, in which mont29 is closed.  Getting there costs no product:
+//   beta * v_sigma      = mont29(v_sigma R, beta 2^266)          (constant prepared on the host)
+//   beta * F::from(j)   = mont29(j, beta 2^522)
+//   v R'                = 32 (v R): a five-bit limb shift (f9_shl5), value below 32 p, well inside the lazy range
+// and getting back costs none either: with inv = (1 / D) R in the library's own form,
+//   z R = mont29(prefix R', mont29(suffix R', inv)),   r_b R = mont29(N_b R', inv),   D R = mont29(D R', R).
+struct GpConsts {
+  F9 beta_sigma;   // beta 2^266 mod p
+  F9 beta_index;   // beta 2^522 mod p
+  F9 gamma;        // gamma R' mod p
+  F9 one;          // R' mod p
+};
+
+__device__ __forceinline__ F9 f9_shfl(const F9& v, int src_lane) {
+  F9 r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.l[i] = __shfl(v.l[i], src_lane);
+  return r;
+}
+
+// 32 a for a normalised a below 2^256: limbs below 2^29 + 2^5, top limb below 2^29
+__device__ __forceinline__ F9 f9_shl5(const F9& a) {
+  F9 r;
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { r.l[i] = ((a.l[i] & ((1u << 24) - 1)) << 5) + c; c = a.l[i] >> 24; }
+  r.l[8] = (a.l[8] << 5) + c;
+  return r;
+}
+
+__device__ __forceinline__ F9 f9_index(uint64_t v) {
+  F9 r;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) r.l[k] = 0;
+  r.l[0] = (uint32_t)v & M29; r.l[1] = (uint32_t)(v >> 29) & M29; r.l[2] = (uint32_t)(v >> 58);
+  return r;
+}
+
+// block_scan_mul on 29-bit limbs (values in R' form, normalised, below 1.5 p after the first product)
+template <int THREADS, bool REVERSE>
+__device__ __forceinline__ F9 block_scan_mul9(F9 v, F9* lds, F9* total, const F9& one) {
+  constexpr int WAVES = THREADS / 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int src = REVERSE ? lane + d : lane - d;
+    const F9 o = f9_shfl(v, src & 63);
+    if (REVERSE ? (src < 64) : (src >= 0)) v = mont29(v, o);
+  }
+  if (lane == (REVERSE ? 0 : 63)) lds[wave] = v;
+  __syncthreads();
+  if (wave == 0) {
+    F9 t = lane < WAVES ? lds[lane] : one;
+#pragma unroll
+    for (int d = 1; d < WAVES; d <<= 1) {
+      const int src = REVERSE ? lane + d : lane - d;
+      const F9 o = f9_shfl(t, src & 63);
+      if (REVERSE ? (src < WAVES) : (src >= 0)) t = mont29(t, o);
+    }
+    if (lane < WAVES) lds[lane] = t;
+  }
+  __syncthreads();
+  *total = lds[REVERSE ? 0 : WAVES - 1];
+  const int prev = REVERSE ? wave + 1 : wave - 1;
+  const bool has_carry = REVERSE ? (prev < WAVES) : (prev >= 0);
+  const F9 carry = lds[has_carry ? prev : 0];
+  __syncthreads();
+  return has_carry ? mont29(v, carry) : v;
+}
+
+// num_j and den_j of one row in R' form, normalised and below 5.5 p (R' itself for a row beyond the circuit);
+// failures recorded with their row.  Bounds in units of p beside the lines.
+__device__ __forceinline__ void gp_row_terms(const GpCols& cols, uint64_t n, uint64_t j, const GpConsts& k9, GpStatus* status, F9& nj, F9& dj) {
+  nj = k9.one; dj = k9.one;
   if (j >= n) return;
-  Fe jraw = fe_zero(); jraw.l[0] = (uint32_t)j; jraw.l[1] = (uint32_t)(j >> 32);
-  const Fe bj_g = fe_add(fe_mul(jraw, beta_r2), gamma);          // beta * F::from(j) + gamma
+  const F9 bj_g = f9_add(mont29(f9_index(j), k9.beta_index), k9.gamma);          // beta * F::from(j) + gamma    < 2.1
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const Fe v = fe_load(cols.v[k], j);
+    const F9 v5 = f9_shl5(f9_from_fe(fe_load(cols.v[k], j)));                    // 32 v                          < 32
     uint64_t sg = cols.sigma[k][j];
     if (sg >= n) { atomicMin(&status->bad_sigma_row, (unsigned long long)j); sg = 0; }
-    const Fe vs = fe_load(cols.v[k], sg);
-    const Fe tn = fe_add(fe_add(v, fe_mul(beta, vs)), gamma);
-    const Fe td = fe_add(v, bj_g);
-    nj = (k == 0) ? tn : fe_mul(nj, tn);
-    dj = (k == 0) ? td : fe_mul(dj, td);
+    const F9 vs = f9_from_fe(fe_load(cols.v[k], sg));
+    F9 tn = f9_add(f9_add(v5, mont29(vs, k9.beta_sigma)), k9.gamma);             // v + beta v_sigma + gamma      < 34.1
+    F9 td = f9_add(v5, bj_g);                                                    // v + beta j + gamma            < 34.1
+    if (k == 0) { f9_normalize(tn); f9_normalize(td); nj = tn; dj = td; }
+    else { nj = mont29(tn, nj); dj = mont29(td, dj); }                           // < 17.5, 9.5, 5.6
   }
-  if (fe_is_zero(dj)) atomicMin(&status->zero_den_row, (unsigned long long)j);
+  if (fe_is_zero(fe_reduce_f9(dj))) atomicMin(&status->zero_den_row, (unsigned long long)j);
+}
+
+// (1 / D) R as limbs, from D R' (zero stays zero; the status word carries the error)
+__device__ __forceinline__ F9 gp_invert(const F9& d_rprime) {
+  const Fe d = fe_reduce_f9(mont29(d_rprime, f9_from_fe(fe_one())));   // D R, canonical
+  return f9_from_fe(fe_inverse_gcd32(d));
 }
 
 // Kernel A: local quotient products L_j -> z_after[j] (= z[j+1] up to the block carry), block ratios r_b -> ratio[b].
-__global__ __launch_bounds__(GP_THREADS, 4) void gp_local_z_kernel(GpCols cols, uint64_t n, Fe beta, Fe gamma, Fe beta_r2,
-                                                                uint64_t* z_after, uint64_t* z0, uint64_t* ratio, GpStatus* status) {
-  __shared__ Fe lds[GP_THREADS / 64];
-  __shared__ Fe edge[GP_THREADS / 64];
-  __shared__ Fe inv_total;
+__global__ __launch_bounds__(GP_THREADS, 4) void gp_local_z_kernel(GpCols cols, uint64_t n, GpConsts k9,
+                                                                   uint64_t* z_after, uint64_t* z0, uint64_t* ratio, GpStatus* status) {
+  __shared__ F9 lds[GP_THREADS / 64];
+  __shared__ F9 edge[GP_THREADS / 64];
+  __shared__ F9 inv_total;
   const uint64_t row0 = ((uint64_t)blockIdx.x * GP_THREADS + threadIdx.x) * GP_ITEMS;
   // the four rows are written out with named values (no array, no loop): the terms must stay in registers from
   // here to the stores at the end
   static_assert(GP_ITEMS == 4, "gp_local_z_kernel spells out four rows per thread");
-  Fe n0, n1, n2, n3, d0, d1, d2, d3;
-  gp_row_terms(cols, n, row0 + 0, beta, gamma, beta_r2, status, n0, d0);
-  gp_row_terms(cols, n, row0 + 1, beta, gamma, beta_r2, status, n1, d1);
-  gp_row_terms(cols, n, row0 + 2, beta, gamma, beta_r2, status, n2, d2);
-  gp_row_terms(cols, n, row0 + 3, beta, gamma, beta_r2, status, n3, d3);
-  // thread-local inclusive prefix of the numerators, inclusive suffix of the denominators
-  n1 = fe_mul(n0, n1); n2 = fe_mul(n1, n2); n3 = fe_mul(n2, n3);
-  d2 = fe_mul(d3, d2); d1 = fe_mul(d2, d1); d0 = fe_mul(d1, d0);
-  Fe tot_n, tot_d;
-  const Fe inc_n = block_scan_mul<GP_THREADS, false>(n3, lds, &tot_n);
-  const Fe inc_d = block_scan_mul<GP_THREADS, true>(d0, lds, &tot_d);
+  F9 n0, n1, n2, n3, d0, d1, d2, d3;
+  gp_row_terms(cols, n, row0 + 0, k9, status, n0, d0);
+  gp_row_terms(cols, n, row0 + 1, k9, status, n1, d1);
+  gp_row_terms(cols, n, row0 + 2, k9, status, n2, d2);
+  gp_row_terms(cols, n, row0 + 3, k9, status, n3, d3);
+  // thread-local inclusive prefix of the numerators, inclusive suffix of the denominators (every product below 1.5 p)
+  n1 = mont29(n0, n1); n2 = mont29(n1, n2); n3 = mont29(n2, n3);
+  d2 = mont29(d3, d2); d1 = mont29(d2, d1); d0 = mont29(d1, d0);
+  F9 tot_n, tot_d;
+  const F9 inc_n = block_scan_mul9<GP_THREADS, false>(n3, lds, &tot_n, k9.one);
+  const F9 inc_d = block_scan_mul9<GP_THREADS, true>(d0, lds, &tot_d, k9.one);
   if (threadIdx.x == 0) {
-    const Fe inv = fe_inverse_gcd32(tot_d);                  // zero stays zero; the status word carries the error
+    const F9 inv = gp_invert(tot_d);
     inv_total = inv;
-    fe_store(ratio, blockIdx.x, fe_mul(tot_n, inv));
+    fe_store(ratio, blockIdx.x, fe_reduce_f9(mont29(tot_n, inv)));
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  Fe ex_n = fe_shfl(inc_n, (lane - 1) & 63);
-  Fe ex_d = fe_shfl(inc_d, (lane + 1) & 63);
+  F9 ex_n = f9_shfl(inc_n, (lane - 1) & 63);
+  F9 ex_d = f9_shfl(inc_d, (lane + 1) & 63);
   if (lane == 63) lds[wave] = inc_n;
   if (lane == 0) edge[wave] = inc_d;
   __syncthreads();
-  if (lane == 0) ex_n = wave == 0 ? fe_one() : lds[wave - 1];
-  if (lane == 63) ex_d = wave == GP_THREADS / 64 - 1 ? fe_one() : edge[wave + 1];
-  const Fe cd = fe_mul(ex_d, inv_total);
+  if (lane == 0) ex_n = wave == 0 ? k9.one : lds[wave - 1];
+  if (lane == 63) ex_d = wave == GP_THREADS / 64 - 1 ? k9.one : edge[wave + 1];
+  const F9 cd = mont29(ex_d, inv_total);          // (suffix of the later threads) / D, in the library's R form
   // L_j = (prefix of numerators up to j) * (suffix of denominators after j) / (all denominators of the block)
-  if (row0 + 0 < n) fe_store(z_after, row0 + 0, fe_mul(fe_mul(ex_n, n0), fe_mul(d1, cd)));
-  if (row0 + 1 < n) fe_store(z_after, row0 + 1, fe_mul(fe_mul(ex_n, n1), fe_mul(d2, cd)));
-  if (row0 + 2 < n) fe_store(z_after, row0 + 2, fe_mul(fe_mul(ex_n, n2), fe_mul(d3, cd)));
-  if (row0 + 3 < n) fe_store(z_after, row0 + 3, fe_mul(fe_mul(ex_n, n3), cd));
+  if (row0 + 0 < n) fe_store(z_after, row0 + 0, fe_reduce_f9(mont29(mont29(ex_n, n0), mont29(d1, cd))));
+  if (row0 + 1 < n) fe_store(z_after, row0 + 1, fe_reduce_f9(mont29(mont29(ex_n, n1), mont29(d2, cd))));
+  if (row0 + 2 < n) fe_store(z_after, row0 + 2, fe_reduce_f9(mont29(mont29(ex_n, n2), mont29(d3, cd))));
+  if (row0 + 3 < n) fe_store(z_after, row0 + 3, fe_reduce_f9(mont29(mont29(ex_n, n3), cd)));
   if (z0 && blockIdx.x == 0 && threadIdx.x == 0) fe_store(z0, 0, fe_one());
 }
 
@@ -154,25 +233,26 @@ __global__ __launch_bounds__(GP_THREADS, 4) void gp_local_z_kernel(GpCols cols, 
 // circuit waits for - its rows' terms, the two scans, the inversion, the finish, all dependent - and with one row
 // per thread the terms and the finish are a quarter as long; the price, one inversion per 256 rows instead of per
 // 1024, is paid in parallel while the GPU has lanes to spare.
-__global__ __launch_bounds__(GP_THREADS) void gp_local_z_small_kernel(GpCols cols, uint64_t n, Fe beta, Fe gamma, Fe beta_r2,
+__global__ __launch_bounds__(GP_THREADS) void gp_local_z_small_kernel(GpCols cols, uint64_t n, GpConsts k9,
                                                                       uint64_t* z_after, uint64_t* z0, uint64_t* ratio, GpStatus* status) {
-  __shared__ Fe lds[GP_THREADS / 64];
-  __shared__ Fe edge[GP_THREADS / 64];
-  __shared__ Fe inv_total;
+  __shared__ F9 lds[GP_THREADS / 64];
+  __shared__ F9 edge[GP_THREADS / 64];
+  __shared__ F9 inv_total;
   const uint64_t j = (uint64_t)blockIdx.x * GP_THREADS + threadIdx.x;
-  Fe nj, dj;
-  gp_row_terms(cols, n, j, beta, gamma, beta_r2, status, nj, dj);
-  Fe tot_n, tot_d;
-  const Fe inc_d = block_scan_mul<GP_THREADS, true>(dj, lds, &tot_d);      // denominators first: the inversion can start
-  if (threadIdx.x == GP_THREADS - 1) inv_total = fe_inverse_gcd32(tot_d);  // (the last wave idles in the next scan's tail)
-  const Fe inc_n = block_scan_mul<GP_THREADS, false>(nj, lds, &tot_n);
+  F9 nj, dj;
+  gp_row_terms(cols, n, j, k9, status, nj, dj);
+  F9 tot_n, tot_d;
+  const F9 inc_d = block_scan_mul9<GP_THREADS, true>(dj, lds, &tot_d, k9.one);
+  if (threadIdx.x == GP_THREADS - 1) inv_total = gp_invert(tot_d);
+  const F9 inc_n = block_scan_mul9<GP_THREADS, false>(nj, lds, &tot_n, k9.one);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  Fe ex_d = fe_shfl(inc_d, (lane + 1) & 63);
+  F9 ex_d = f9_shfl(inc_d, (lane + 1) & 63);
   if (lane == 0) edge[wave] = inc_d;
   __syncthreads();
-  if (lane == 63) ex_d = wave == GP_THREADS / 64 - 1 ? fe_one() : edge[wave + 1];
-  if (threadIdx.x == 0) fe_store(ratio, blockIdx.x, fe_mul(tot_n, inv_total));
-  if (j < n) fe_store(z_after, j, fe_mul(inc_n, fe_mul(ex_d, inv_total)));     // prefix of numerators * suffix of denominators / all denominators
+  if (lane == 63) ex_d = wave == GP_THREADS / 64 - 1 ? k9.one : edge[wave + 1];
+  if (threadIdx.x == 0) fe_store(ratio, blockIdx.x, fe_reduce_f9(mont29(tot_n, inv_total)));
+  // prefix of numerators * (suffix of denominators / all denominators)
+  if (j < n) fe_store(z_after, j, fe_reduce_f9(mont29(inc_n, mont29(ex_d, inv_total))));
   if (z0 && blockIdx.x == 0 && threadIdx.x == 0) fe_store(z0, 0, fe_one());
 }
 
