@@ -86,7 +86,10 @@ SIGNATURES = {
     "plk_dev_gate_constraint_eval": (C.c_int, [C.c_void_p, C.c_void_p, u64pp, u64pp, C.c_size_t, u64p]),
     "plk_dev_perm_constraint_eval": (C.c_int, [C.c_void_p, C.c_void_p, u64p, u64pp, u64pp, C.c_size_t, u64p, u64p, C.c_size_t, u64p]),
     "plk_dev_perm_constraint_eval_range": (C.c_int, [C.c_void_p, C.c_void_p, u64p, u64pp, u64pp, C.c_size_t, C.c_size_t, u64p, u64p, C.c_size_t, u64p]),
-    "plk_dev_round23": (C.c_int, [C.c_void_p, C.c_void_p, u64pp, u64pp, u64pp, C.c_size_t, C.c_size_t, u64p, u64p, C.c_size_t, u64p, u64p, u64p]),
+    # (every pointer as a plain address: the call is made thousands of times a second for small circuits, and a
+    # typed ctypes pointer per argument would cost more than the call)
+    "plk_dev_round23": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p,
+                                  C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "plk_dev_status": (C.c_int, [C.c_void_p, C.c_void_p]),
     "plk_profile_begin": (None, [C.c_void_p]),
     "plk_profile_end": (C.c_char_p, [C.c_void_p]),

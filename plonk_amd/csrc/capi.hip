@@ -808,7 +808,12 @@ int launch_grand_product(plk_ctx* ctx, hipStream_t s, const uint64_t* const wire
                          z_out + 4, z_out, ratio, ctx->status_dev);
   }
   HIP_TRY(ctx, hipGetLastError());
-  if (nb > 1) {
+  if (nb > 1 && small) {
+    static_assert(GP_SMALL_ROWS / GP_THREADS <= GP_THREADS, "gp_apply_small_kernel: one thread per earlier block");
+    ProfScope ps(ctx, s, "gp_apply_small_kernel", 0.0, (double)n);
+    hipLaunchKernelGGL(gp_apply_small_kernel, dim3((unsigned)(nb - 1)), dim3(GP_THREADS), 0, s, z_out + 4, (uint64_t)n, (const uint64_t*)ratio);
+    HIP_TRY(ctx, hipGetLastError());
+  } else if (nb > 1) {
     {
       ProfScope ps(ctx, s, "gp_ratio_scan_kernel", 0.0);
       hipLaunchKernelGGL(gp_ratio_scan_kernel, dim3(1), dim3(GP_SCAN_THREADS), 0, s, ratio, (uint32_t)nb);
@@ -816,8 +821,7 @@ int launch_grand_product(plk_ctx* ctx, hipStream_t s, const uint64_t* const wire
     HIP_TRY(ctx, hipGetLastError());
     {
       ProfScope ps(ctx, s, "gp_apply_kernel", 0.0, (double)n);
-      if (small) hipLaunchKernelGGL(gp_apply_kernel<1>, dim3((unsigned)(nb - 1)), dim3(GP_THREADS), 0, s, z_out + 4, (uint64_t)n, (const uint64_t*)ratio);
-      else hipLaunchKernelGGL(gp_apply_kernel<GP_ITEMS>, dim3((unsigned)(nb - 1)), dim3(GP_THREADS), 0, s, z_out + 4, (uint64_t)n, (const uint64_t*)ratio);
+      hipLaunchKernelGGL(gp_apply_kernel<GP_ITEMS>, dim3((unsigned)(nb - 1)), dim3(GP_THREADS), 0, s, z_out + 4, (uint64_t)n, (const uint64_t*)ratio);
     }
     HIP_TRY(ctx, hipGetLastError());
   }
@@ -1746,7 +1750,7 @@ int plk_ctx_create(int device, plk_ctx** out) {
     CTX_TRY(hipFuncGetAttributes(&fa, (const void*)gp_local_z_kernel));
     CTX_TRY(hipFuncGetAttributes(&fa, (const void*)gp_ratio_scan_kernel));
     CTX_TRY(hipFuncGetAttributes(&fa, (const void*)gp_apply_kernel<GP_ITEMS>));
-    CTX_TRY(hipFuncGetAttributes(&fa, (const void*)gp_apply_kernel<1>));
+    CTX_TRY(hipFuncGetAttributes(&fa, (const void*)gp_apply_small_kernel));
     CTX_TRY(hipFuncGetAttributes(&fa, (const void*)gp_local_z_small_kernel));
   }
   CTX_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES));

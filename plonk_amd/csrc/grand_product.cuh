@@ -287,6 +287,18 @@ __global__ __launch_bounds__(GP_THREADS) void gp_apply_kernel(uint64_t* z_after,
   }
 }
 
+// Kernels B and C in one for small circuits (blocks of GP_THREADS rows, at most GP_THREADS of them): every workgroup
+// multiplies the ratios of the blocks before its own together by itself - a few dependent products - instead of
+// waiting for a one-workgroup scan kernel in between.  `ratio` is only read.
+__global__ __launch_bounds__(GP_THREADS) void gp_apply_small_kernel(uint64_t* z_after, uint64_t n, const uint64_t* ratio) {
+  __shared__ Fe lds[GP_THREADS / 64];
+  const uint32_t b = blockIdx.x + 1;
+  Fe c;
+  block_scan_mul<GP_THREADS, false>(threadIdx.x < b ? fe_load(ratio, threadIdx.x) : fe_one(), lds, &c);
+  const uint64_t j = (uint64_t)b * GP_THREADS + threadIdx.x;
+  if (j < n) fe_store(z_after, j, fe_mul(fe_load(z_after, j), c));
+}
+
 // ---- row-range form (rows split over several GPUs): terms, block products, carries, finish ---------------------
 
 // Kernel 1: per-row numerator / denominator terms and per-block products, for the rows

@@ -25,10 +25,10 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 def _table(ts: Sequence[Optional[torch.Tensor]]):
-    arr = (_lib.u64p * len(ts))()
-    for i, t in enumerate(ts):
-        arr[i] = _ptr(t)
-    return arr
+    """A C array of column pointers (one ctypes cast for the whole table: a cast per pointer costs microseconds each,
+    which is what a small circuit's call would then spend most of its time on)."""
+    arr = (C.c_void_p * len(ts))(*[t.data_ptr() if t is not None else None for t in ts])
+    return C.cast(arr, _lib.u64pp)
 
 
 def _host_fe(x) -> np.ndarray:
@@ -51,6 +51,14 @@ class DeviceCircuit:
     sigma: List[torch.Tensor]
     beta: np.ndarray
     gamma: np.ndarray
+    _tabs: Optional[tuple] = None
+
+    def tables(self):
+        """(wires, selectors, sigma) pointer tables, built on first use: the columns of an uploaded circuit stay where
+        they are (beta and gamma may be replaced at will, they are passed by value each call)."""
+        if self._tabs is None:
+            self._tabs = (_table(self.wires), _table([self.selectors.get(k) for k in AST_KINDS]), _table(self.sigma))
+        return self._tabs
 
 
 class DeviceProver:
@@ -208,10 +216,11 @@ class DeviceProver:
     def round23(self, dc: DeviceCircuit, N: int, z_shift: int = 1, out=None):
         """Enqueue rounds 2+3 for one circuit; returns (z [n+1], gate [N], perm [N]) device tensors."""
         z, g, p = out if out is not None else (self.empty(dc.n + 1), self.empty(N), self.empty(N))
-        sels = [dc.selectors.get(k) for k in AST_KINDS]
-        self.ctx.check(self.lib.plk_dev_round23(self.ctx.handle, self._stream(), _table(dc.wires), _table(sels), _table(dc.sigma),
-                                                dc.n, N, dc.beta.ctypes.data_as(_lib.u64p), dc.gamma.ctypes.data_as(_lib.u64p),
-                                                z_shift, _ptr(z), _ptr(g), _ptr(p)))
+        wires, sels, sigma = dc.tables()
+        rc = self.lib.plk_dev_round23(self.ctx.handle, self._stream(), wires, sels, sigma, dc.n, N, dc.beta.ctypes.data, dc.gamma.ctypes.data,
+                                      z_shift, z.data_ptr(), g.data_ptr(), p.data_ptr())
+        if rc:
+            self.ctx.check(rc)
         return z, g, p
 
     # -- pieces of the multi-GPU paths (plonk_amd.dist)
