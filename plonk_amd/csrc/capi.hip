@@ -1538,10 +1538,16 @@ int download(plk_ctx* ctx, void* host, const void* src, size_t bytes) {
   return PLK_OK;
 }
 
+// Staging buffers of a host entry point.  Going out of scope waits for the context's stream: copies from and to the
+// CALLER's arrays are asynchronous when those are page-locked, and an entry point that returns early with an error
+// must not leave one in flight behind it (after a successful call the stream is idle already and the wait is free).
 struct Staged {
   plk_ctx* ctx;
   int used = 0;
   explicit Staged(plk_ctx* c) : ctx(c) {}
+  Staged(const Staged&) = delete;
+  Staged& operator=(const Staged&) = delete;
+  ~Staged() { (void)hipStreamSynchronize(ctx->stream); }
   int alloc(size_t bytes, void** out) {
     return ws_get(ctx, "stage" + std::to_string(used++), std::max<size_t>(bytes, 32), out);
   }
@@ -1573,6 +1579,12 @@ int round23_host_pipelined(plk_ctx* ctx, const uint64_t* const wires[4], const u
   int rc;
   hipStream_t s = ctx->stream, sa = ctx->aux, up = ctx->copy_up, down = ctx->copy_down;
   enum { EV_W = 0, EV_S, EV_Z, EV_GATE, EV_PERM, EV_SEL0 };   // EV_SEL0 .. EV_SEL0 + 2
+  // every way out of this function - errors included - leaves no copy from or to the caller's arrays in flight
+  // (declared before `st`: destroyed after it, so the context's own stream has been waited for by then)
+  struct Drain {
+    plk_ctx* c;
+    ~Drain() { (void)hipStreamSynchronize(c->aux); (void)hipStreamSynchronize(c->copy_up); (void)hipStreamSynchronize(c->copy_down); }
+  } drain{ctx};
   Staged st(ctx);
   void *dw[4], *dsg[4], *dsel[9] = {nullptr}, *dz, *dg = nullptr, *dp = nullptr;
   for (int k = 0; k < 4; ++k) { if ((rc = st.alloc(n * ELEM, &dw[k]))) return rc; if ((rc = st.alloc(n * 8, &dsg[k]))) return rc; }
@@ -2482,6 +2494,8 @@ int plk_round23(plk_ctx* ctx, const uint64_t* const wires[4], const uint64_t* co
   if ((rc = check_domain(ctx, N, &l2))) return rc;
   if (!wires || !sigma || !beta || !gamma) return fail(ctx, PLK_ERR_ARG, "null pointer");
   for (int k = 0; k < 4; ++k) if (!wires[k] || !sigma[k]) return fail(ctx, PLK_ERR_ARG, "null column pointer");
+  if (!fe_is_canonical(fe_from_limbs64(beta)) || !fe_is_canonical(fe_from_limbs64(gamma)))   // before anything is uploaded
+    return fail(ctx, PLK_ERR_ARG, "beta/gamma not reduced mod p");
   if (n <= N && r23_coset_form(n, N, l1))
     return round23_host_pipelined(ctx, wires, sel, sigma, n, N, beta, gamma, z_shift, z_out, gate_out, perm_out);
   Staged st(ctx);
