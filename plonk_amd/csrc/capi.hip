@@ -162,6 +162,8 @@ struct plk_ctx {
   std::string last_error;
   long long last_row = -1;
   // optional per-launch timing (plk_profile_*): one event pair per kernel launch
+  int two_pass_max_log = 20;                     // transforms up to 2^this take two passes, larger ones three (measured: 2^21, 2^22 are 3-8 % slower in two)
+  int first_radix_log = 0;                       // measurement knob: the first radix of two-pass plans (0 = even split)
   bool profiling = false;
   struct ProfRec { std::string label; hipEvent_t e0, e1; double alg_bytes; double products; };
   std::vector<ProfRec> prof;
@@ -281,9 +283,14 @@ int get_plan(plk_ctx* ctx, int log_n, bool inverse, hipStream_t s, NttPlan** out
     ~PlanGuard() { if (p) free_plan_tables(*p); }
   } guard{&plan};
   plan.log_n = log_n;
-  plan.npass = log_n <= NTT_TILE_LOG ? 1 : (log_n <= 16 ? 2 : 3);
+  plan.npass = log_n <= NTT_TILE_LOG ? 1 : (log_n <= ctx->two_pass_max_log ? 2 : 3);
   const int base = log_n / plan.npass, rem = log_n % plan.npass;
   for (int p = 0; p < plan.npass; ++p) plan.log_r[p] = base + (p < rem ? 1 : 0);
+  if (plan.npass == 2 && ctx->first_radix_log > 0 && ctx->first_radix_log <= NTT_TILE_LOG && log_n - ctx->first_radix_log <= NTT_TILE_LOG &&
+      log_n - ctx->first_radix_log >= 3 && ctx->first_radix_log >= 3) {
+    plan.log_r[0] = ctx->first_radix_log;
+    plan.log_r[1] = log_n - ctx->first_radix_log;
+  }
 
   Fe w = root_of_unity(log_n);
   Fe wm = root_of_unity(NTT_MASTER_LOG);
@@ -479,7 +486,8 @@ int launch_ntt(plk_ctx* ctx, hipStream_t s, const uint64_t* const* in, const uin
     // + the inter-pass twiddle (two products through the two-level table), + the coset prescale in the first pass
     const double per_elem = tile_products(lr, p == 0 && quarter_in) + (plan->tab.tw_full[p] ? 1.0 : 2.0) + ((p == 0 && cosets) ? 1.0 : 0.0);
     ProfScope ps(ctx, s, "ntt_pass_kernel" + tag + "/p" + std::to_string(p), alg_share, per_elem * elems + (p == 0 ? u64_products : 0.0));
-    hipLaunchKernelGGL(ntt_pass_kernel, dim3((unsigned)(tiles * slots)), dim3(NTT_THREADS), lds_bytes, s, a);
+    if (ntt_big_radix(plan->tab.master_sh, lr)) hipLaunchKernelGGL(ntt_pass_kernel<true>, dim3((unsigned)(tiles * slots)), dim3(NTT_THREADS), lds_bytes, s, a);
+    else hipLaunchKernelGGL(ntt_pass_kernel<false>, dim3((unsigned)(tiles * slots)), dim3(NTT_THREADS), lds_bytes, s, a);
     HIP_TRY(ctx, hipGetLastError());
   }
   {
@@ -500,7 +508,8 @@ int launch_ntt(plk_ctx* ctx, hipStream_t s, const uint64_t* const* in, const uin
     const unsigned tiles = 1u << (log_n - a.log_r - a.log_c);
     const double per_elem = tile_products(a.log_r, P == 1 && quarter_in) + (plan->tab.scale ? 1.0 : 0.0) + ((P == 1 && cosets) ? 1.0 : 0.0);
     ProfScope ps(ctx, s, "ntt_final_kernel" + tag, alg_share, per_elem * elems + (P == 1 ? u64_products : 0.0));
-    hipLaunchKernelGGL(ntt_final_kernel, dim3(tiles, (unsigned)slots), dim3(NTT_THREADS), lds_bytes, s, a);
+    if (ntt_big_radix(plan->tab.master_sh, a.log_r)) hipLaunchKernelGGL(ntt_final_kernel<true>, dim3(tiles, (unsigned)slots), dim3(NTT_THREADS), lds_bytes, s, a);
+    else hipLaunchKernelGGL(ntt_final_kernel<false>, dim3(tiles, (unsigned)slots), dim3(NTT_THREADS), lds_bytes, s, a);
     HIP_TRY(ctx, hipGetLastError());
   }
   return PLK_OK;
@@ -1732,6 +1741,8 @@ int plk_ctx_create(int device, plk_ctx** out) {
   }
   plk_ctx* ctx = new (std::nothrow) plk_ctx();
   if (!ctx) return PLK_ERR_NOMEM;
+  if (const char* e = getenv("PLONK_NTT_FIRST_RADIX_LOG")) ctx->first_radix_log = atoi(e);
+  if (const char* e = getenv("PLONK_NTT_TWO_PASS_MAX_LOG")) ctx->two_pass_max_log = std::max(12, std::min(atoi(e), 2 * NTT_TILE_LOG));   // measurement knob
   ctx->device = device;
 #define CTX_TRY(expr)                                                                           \
   do {                                                                                          \
@@ -1765,8 +1776,10 @@ int plk_ctx_create(int device, plk_ctx** out) {
     CTX_TRY(hipFuncGetAttributes(&fa, (const void*)gp_apply_small_kernel));
     CTX_TRY(hipFuncGetAttributes(&fa, (const void*)gp_local_z_small_kernel));
   }
-  CTX_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES));
-  CTX_TRY(hipFuncSetAttribute((const void*)ntt_final_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES));
+  CTX_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES));
+  CTX_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES));
+  CTX_TRY(hipFuncSetAttribute((const void*)ntt_final_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES));
+  CTX_TRY(hipFuncSetAttribute((const void*)ntt_final_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES));
   CTX_TRY(hipFuncSetAttribute((const void*)ntt_fs_kernel<FS_A_FIRST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES));
   CTX_TRY(hipFuncSetAttribute((const void*)ntt_fs_kernel<FS_A_LAST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES));
   CTX_TRY(hipFuncSetAttribute((const void*)ntt_fs_kernel<FS_B_FIRST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES));

@@ -31,7 +31,9 @@ constexpr int NTT_THREADS = 512;
 constexpr int NTT_MAX_BATCH = 24;           // columns per launch
 constexpr int NTT_MASTER_LOG = 11;          // per-tile twiddles: omega_{2^11}^e, e < 2^10
 constexpr int NTT_LDS_TW_LOG = 7;           // per-tile twiddles kept in LDS when the radix is <= 2^8
-constexpr size_t NTT_LDS_BYTES = ((size_t)NTT_TILE + (1 << NTT_LDS_TW_LOG)) * 36;   // 9 words per element
+constexpr int NTT_LDS_TW_RECORDS = 192;     // the LDS twiddle area (tile_transform says how each radix fills it)
+constexpr size_t NTT_LDS_BYTES = ((size_t)NTT_TILE + NTT_LDS_TW_RECORDS) * 36;   // 9 words per element; 2 workgroups per CU
+static_assert(2 * ((NTT_LDS_BYTES + 511) / 512 * 512) <= 160 * 1024, "two workgroups of the transform kernels share a CU's LDS");
 constexpr int TW_WORDS = 12;                // one twiddle record (9 limbs + padding)
 
 enum NttInputKind : uint32_t { NTT_IN_FIELD = 0, NTT_IN_U64 = 1 };
@@ -120,10 +122,14 @@ __device__ __forceinline__ F9 load_input(const uint64_t* in, uint64_t idx, bool 
 // Outputs are lazy: limbs < 1.3 * 2^31, value < (4 + 2 log_r) p.
 //
 // SH = true: the butterfly products of the later steps use the precomputed-quotient form (shoup29_x2, 143
-// multiply-adds instead of 153) with twiddle pairs (w, wq) from `master_sh`; the caller picks it when the pairs of
-// this radix fit the LDS twiddle area (radix <= 2^7).  Same values, same bounds (both products return < 1.91 p).
+// multiply-adds instead of 153) with twiddle pairs (w, wq) from `master_sh` kept in the LDS twiddle area.
+//   radix <= 2^7:  the area holds the radix's whole table as pairs (at most 64: records 0-63 w, 64-127 wq);
+//   radix >= 2^9:  32 pairs (records 0-31 w, 32-63 wq) serve the steps up to h = 16 (omega_{4h}^x with 4h <= 64 is a
+//                  power of omega_64 whatever the radix), 128 plain twiddles (records 64-191, the powers of
+//                  omega_256) serve the step h = 64, and the steps beyond take plain twiddles from memory.
+// Same values, same bounds (both products return < 1.91 p).  See ntt_use_sh for who picks it.
 struct TwPair { F9 w, q; };
-template <bool SH, class Load, class Store>
+template <bool SH, bool BIG, class Load, class Store>
 __device__ __forceinline__ void tile_transform(const Tile& t, int log_r, int log_c, const uint32_t* master, const uint32_t* master_sh,
                                                bool quarter, Load load, Store store) {
   const int cmask = (1 << log_c) - 1;
@@ -141,24 +147,33 @@ __device__ __forceinline__ void tile_transform(const Tile& t, int log_r, int log
   }
   // the 2^(log_r - 1) twiddles of this radix, omega_R^j, copied next to the tile when they fit
   // (first used after the barrier that ends the first step)
-  const Tile ltw(reinterpret_cast<unsigned char*>(t.A) + (size_t)NTT_TILE * 36, 1 << NTT_LDS_TW_LOG);
+  const Tile ltw(reinterpret_cast<unsigned char*>(t.A) + (size_t)NTT_TILE * 36, NTT_LDS_TW_RECORDS);
   const bool tw_lds = log_r - 1 <= NTT_LDS_TW_LOG;
-  constexpr int SH_SLOTS = 1 << (NTT_LDS_TW_LOG - 1);       // pairs that fit the LDS twiddle area
+  static_assert(SH || !BIG, "BIG is a form of SH");
+  constexpr bool big = BIG;                                  // radix >= 2^9
+  constexpr int SH_SLOTS = big ? 32 : 64;                    // pairs in the LDS twiddle area
+  const int sh_shift = big ? log_r - 6 : 0;                  // radix index -> index into the pairs (powers of omega_64)
+  constexpr int MID_BASE = 64, MID_LOG = 8;                  // big: plain powers of omega_256 behind the pairs
   if (SH) {
     if (log_r > 2) {
-      const int count = 1 << (log_r - 1);                    // <= SH_SLOTS, the caller's condition for SH
+      const int count = min(1 << (log_r - 1), SH_SLOTS);
       for (int j = threadIdx.x; j < 2 * count; j += NTT_THREADS) {
         const int e = j >> 1, half = j & 1;
-        ltw.put(half * SH_SLOTS + e, f9_load_tw(master_sh, (((size_t)e << (NTT_MASTER_LOG - log_r)) << 1) + half));
+        ltw.put(half * SH_SLOTS + e, f9_load_tw(master_sh, (((size_t)e << (NTT_MASTER_LOG - log_r + sh_shift)) << 1) + half));
       }
+      if (big)
+        for (int j = threadIdx.x; j < (1 << (MID_LOG - 1)); j += NTT_THREADS)
+          ltw.put(MID_BASE + j, f9_load_tw(master, (size_t)j << (NTT_MASTER_LOG - MID_LOG)));
     }
   } else if (tw_lds && log_r > 2) {
     const int count = 1 << (log_r - 1);
     for (int j = threadIdx.x; j < count; j += NTT_THREADS)
       ltw.put(j, f9_load_tw(master, (size_t)j << (NTT_MASTER_LOG - log_r)));
   }
-  auto tw = [&](int idx) { return tw_lds ? ltw.get(idx) : f9_load_tw(master, (size_t)idx << (NTT_MASTER_LOG - log_r)); };
-  auto tw2 = [&](int idx) { TwPair r; r.w = ltw.get(idx); r.q = ltw.get(SH_SLOTS + idx); return r; };
+  // plain twiddles: from LDS when this radix keeps them there (never together with the pairs), else from memory
+  auto tw = [&](int idx) { return (!SH && tw_lds) ? ltw.get(idx) : f9_load_tw(master, (size_t)idx << (NTT_MASTER_LOG - log_r)); };
+  auto tw_mid = [&](int idx) { return ltw.get(MID_BASE + (idx >> (log_r - MID_LOG))); };   // big, steps with 4h <= 256
+  auto tw2 = [&](int idx) { TwPair r; r.w = ltw.get(idx >> sh_shift); r.q = ltw.get(SH_SLOTS + (idx >> sh_shift)); return r; };
   const int groups = 1 << (log_r + log_c - 2);
   const int quarter_rows = 1 << (log_r - 2);
 
@@ -193,6 +208,8 @@ __device__ __forceinline__ void tile_transform(const Tile& t, int log_r, int log
   for (; lh + 1 < log_r; lh += 2) {   // two stages per step
     const int h = 1 << lh;
     const bool last = lh + 2 == log_r;
+    const bool sh = SH && 2 * h <= SH_SLOTS;              // this step's twiddles are among the pairs
+    const bool mid = SH && big && !sh && 4 * h <= (1 << MID_LOG);   // ... or among the plain ones behind them
     for (int g = threadIdx.x; g < groups; g += NTT_THREADS) {
       const int c = g & cmask, q = g >> log_c;
       const int j = q & (h - 1);
@@ -200,15 +217,16 @@ __device__ __forceinline__ void tile_transform(const Tile& t, int log_r, int log
       const int e0 = (i0 << log_c) + c, step = h << log_c;
       const F9 x0 = t.get(e0), x1 = t.get(e0 + step), x2 = t.get(e0 + 2 * step), x3 = t.get(e0 + 3 * step);
       F9 t1, t3;
-      if (SH) { const TwPair w1 = tw2(j << (log_r - 1 - lh)); shoup29_x2(x1, w1.w, w1.q, x3, w1.w, w1.q, t1, t3); }   // omega_{2h}^j
-      else { const F9 w1 = tw(j << (log_r - 1 - lh)); mont29_x2(x1, w1, x3, w1, t1, t3); }
+      if (SH && sh) { const TwPair w1 = tw2(j << (log_r - 1 - lh)); shoup29_x2(x1, w1.w, w1.q, x3, w1.w, w1.q, t1, t3); }   // omega_{2h}^j
+      else { const int i1 = j << (log_r - 1 - lh); const F9 w1 = mid ? tw_mid(i1) : tw(i1); mont29_x2(x1, w1, x3, w1, t1, t3); }
       const F9 a0 = f9_add(x0, t1), a1 = f9_sub_q2(x0, t1), a2 = f9_add(x2, t3), a3 = f9_sub_q2(x2, t3);
       F9 s2, s3;                                                                          // omega_{4h}^j, omega_{4h}^(j+h)
-      if (SH) {
+      if (SH && sh) {
         const TwPair w2 = tw2(j << (log_r - 2 - lh)), w3 = tw2((j + h) << (log_r - 2 - lh));
         shoup29_x2(a2, w2.w, w2.q, a3, w3.w, w3.q, s2, s3);
       } else {
-        const F9 w2 = tw(j << (log_r - 2 - lh)), w3 = tw((j + h) << (log_r - 2 - lh));
+        const int i2 = j << (log_r - 2 - lh), i3 = (j + h) << (log_r - 2 - lh);
+        const F9 w2 = mid ? tw_mid(i2) : tw(i2), w3 = mid ? tw_mid(i3) : tw(i3);
         mont29_x2(a2, w2, a3, w3, s2, s3);
       }
       F9 y0 = f9_add(a0, s2), y2 = f9_sub_q2(a0, s2), y1 = f9_add(a1, s3), y3 = f9_sub_q2(a1, s3);
@@ -237,7 +255,7 @@ __device__ __forceinline__ void tile_transform(const Tile& t, int log_r, int log
       const F9 xa = t.get((row[0] << log_c) + col[0]), xb = t.get((row[1] << log_c) + col[1]);
       const F9 ya = t.get(((row[0] + h) << log_c) + col[0]), yb = t.get(((row[1] + h) << log_c) + col[1]);
       F9 ta, tb;
-      if (SH) {
+      if (SH && h <= SH_SLOTS) {
         const TwPair wa = tw2(jj[0] << (log_r - 1 - lh)), wb = tw2(jj[1] << (log_r - 1 - lh));
         shoup29_x2(ya, wa.w, wa.q, yb, wb.w, wb.q, ta, tb);
       } else {
@@ -247,6 +265,19 @@ __device__ __forceinline__ void tile_transform(const Tile& t, int log_r, int log
       if (second) { store(row[1], col[1], f9_add(xb, tb)); store(row[1] + h, col[1], f9_sub_q2(xb, tb)); }
     }
   }
+}
+
+// Which form a pass of radix 2^log_r takes: pairs in LDS for every step (radix <= 2^7) or for the steps that fit
+// (radix >= 2^9, the rest from LDS and memory as plain twiddles: BIG, a kernel instantiation of its own, so that the
+// common radices keep their register budget); a radix of 2^8 keeps its 128 plain twiddles in LDS.
+__host__ __device__ __forceinline__ bool ntt_big_radix(const uint32_t* master_sh, int log_r) { return master_sh && log_r >= NTT_LDS_TW_LOG + 2; }
+
+template <bool BIG, class Load, class Store>
+__device__ __forceinline__ void tile_transform_any(const Tile& t, int log_r, int log_c, const uint32_t* master, const uint32_t* master_sh,
+                                                   bool quarter, Load load, Store store) {
+  if constexpr (BIG) tile_transform<true, true>(t, log_r, log_c, master, master_sh, quarter, load, store);
+  else if (master_sh && log_r >= 3 && log_r <= NTT_LDS_TW_LOG) tile_transform<true, false>(t, log_r, log_c, master, master_sh, quarter, load, store);
+  else tile_transform<false, false>(t, log_r, log_c, master, master_sh, quarter, load, store);
 }
 
 // omega_N^E (twiddle record) from the two-level table
@@ -284,6 +315,7 @@ struct NttPassArgs {
 // cosets) run on one XCD at about the same time, so the inter-pass twiddle and prescale records
 // of that position, and in coset mode the input tile shared by a column's cosets, come from L2
 // instead of once per slot from memory.
+template <bool BIG>
 __global__ __launch_bounds__(NTT_THREADS, 4) void ntt_pass_kernel(const NttPassArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const Tile tile(lds_raw);
@@ -323,8 +355,7 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void ntt_pass_kernel(const NttPassA
                            : twiddle_two_level(hi, a.tab.tw_lo, a.tab.lo_bits, ((uint64_t)k * q) << shift);
         fe_store(out, base + ((uint64_t)k << log_inner) + c, fe_pack_f9(mont29(v, tw)));
       };
-  if (a.tab.master_sh && log_r >= 3 && log_r <= NTT_LDS_TW_LOG) tile_transform<true>(tile, log_r, log_c, a.tab.master, a.tab.master_sh, quarter, load, store);
-  else tile_transform<false>(tile, log_r, log_c, a.tab.master, a.tab.master_sh, quarter, load, store);
+  tile_transform_any<BIG>(tile, log_r, log_c, a.tab.master, a.tab.master_sh, quarter, load, store);
 }
 
 struct NttFinalArgs {
@@ -347,6 +378,7 @@ struct NttFinalArgs {
 // Row o_c = (k1_0 + c) * R2 + k2 of the pass-major buffer feeds column c of the tile; a thread of the
 // first step reads its four elements of that row straight from memory (32-byte pieces; the row's
 // lines are shared by neighbouring waves of the workgroup through the vector cache).
+template <bool BIG>
 __global__ __launch_bounds__(NTT_THREADS, 4) void ntt_final_kernel(const NttFinalArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const Tile tile(lds_raw);
@@ -377,8 +409,7 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void ntt_final_kernel(const NttFina
         const uint64_t dst = (k1_0 + c) + (k2 << a.log_r1) + ((uint64_t)k << (a.log_r1 + a.log_r2));
         fe_store(out, dst, fe_reduce_f9(scaled ? mont29(v, sc) : v));
       };
-  if (a.tab.master_sh && log_r >= 3 && log_r <= NTT_LDS_TW_LOG) tile_transform<true>(tile, log_r, log_c, a.tab.master, a.tab.master_sh, quarter, load, store);
-  else tile_transform<false>(tile, log_r, log_c, a.tab.master, a.tab.master_sh, quarter, load, store);
+  tile_transform_any<BIG>(tile, log_r, log_c, a.tab.master, a.tab.master_sh, quarter, load, store);
 }
 
 // ---- the local phases of a four-step transform sharded over G ranks ---------------------------------------------
@@ -434,8 +465,7 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void ntt_fs_kernel(const FsArgs a) 
   auto addr_b = [&](uint64_t k1l, uint64_t n2) { return ((n2 >> log_c2) << (a.log_r1 + log_c2)) + (k1l << log_c2) + (n2 & cmask2); };
   const uint32_t wg = blockIdx.x;
   auto run = [&](auto load, auto store) {
-    if (a.master_sh && log_r >= 3 && log_r <= NTT_LDS_TW_LOG) tile_transform<true>(tile, log_r, log_c, a.master, a.master_sh, false, load, store);
-    else tile_transform<false>(tile, log_r, log_c, a.master, a.master_sh, false, load, store);
+    tile_transform_any<false>(tile, log_r, log_c, a.master, a.master_sh, false, load, store);   // (sub-transform radices stay below 2^9)
   };
   if constexpr (MODE == FS_A_FIRST) {
     const uint64_t colblocks = 1ull << (log_c2 - log_c);

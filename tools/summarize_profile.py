@@ -25,10 +25,12 @@ BY_GRID = {
     "gp_local_z_kernel": [["gp_local_z_kernel"]],
     "gp_ratio_scan_kernel": [["gp_ratio_scan_kernel"]],
     "gp_apply_kernel": [["gp_apply_kernel"]],
-    "ntt_pass_kernel": [["ntt_pass_kernel/intt20/side/p0", "ntt_pass_kernel/intt20/side/p1"],
-                        ["ntt_pass_kernel/lde20to22/side/p0", "ntt_pass_kernel/lde20to22/side/p1"],
-                        ["ntt_pass_kernel/intt20/p0", "ntt_pass_kernel/intt20/p1"],
-                        ["ntt_pass_kernel/lde20to22/p0", "ntt_pass_kernel/lde20to22/p1"]],
+    # (a 2^20-point transform takes two passes: one ntt_pass launch and the final one; with three passes each
+    # list here held p0 and p1)
+    "ntt_pass_kernel": [["ntt_pass_kernel/intt20/side/p0"],
+                        ["ntt_pass_kernel/lde20to22/side/p0"],
+                        ["ntt_pass_kernel/intt20/p0"],
+                        ["ntt_pass_kernel/lde20to22/p0"]],
     "ntt_final_kernel": [["ntt_final_kernel/intt20/side"], ["ntt_final_kernel/lde20to22/side"],
                          ["ntt_final_kernel/intt20"], ["ntt_final_kernel/lde20to22"]],
     "gate_constraint_coset_kernel": [["gate_constraint_coset_kernel"]],
