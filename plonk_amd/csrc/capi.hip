@@ -50,7 +50,17 @@ struct NttPlan {
   int npass = 1;
   int log_r[3] = {0, 0, 0};
   NttTables tab{};
-  DevBuf master, hi, hi_scaled, lo, scale, from_u64, full[2], prescale4;
+  DevBuf master, hi, hi_scaled, lo, scale, full[2], prescale4;
+};
+
+// What launch_ntt does with its NTT_IN_U64 columns beyond F::from: an optional constant every such column is
+// multiplied by (Montgomery form; the transforms are linear, so the outputs are the constant times the column's),
+// and an optional place for the converted inputs (canonical elements, column b of the batch at
+// conv_out + (b - conv_first) * n_in elements).
+struct U64Opt {
+  const Fe* scale = nullptr;
+  uint64_t* conv_out = nullptr;
+  int conv_first = 0;
 };
 
 }  // namespace
@@ -268,8 +278,16 @@ int alloc_table(plk_ctx* ctx, DevBuf& buf, uint64_t count, const Fe& base, int s
 }
 
 void free_plan_tables(NttPlan& p) {
-  for (DevBuf* b : {&p.master, &p.hi, &p.hi_scaled, &p.lo, &p.scale, &p.from_u64, &p.full[0], &p.full[1], &p.prescale4})
+  for (DevBuf* b : {&p.master, &p.hi, &p.hi_scaled, &p.lo, &p.scale, &p.full[0], &p.full[1], &p.prescale4})
     if (b->p) { (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
+}
+
+// The conversion record of raw 64-bit integers (ntt.cuh, NttU64): 2^(256+261) mod p as a plain integer - multiplying
+// a raw integer x by it (mont29) gives x * 2^256, the element F::from(x) - times `scale` if one is given.
+void u64_record(const Fe* scale, uint32_t rec[TW_WORDS]) {
+  static const Fe c = [] { Fe v = fe_one(); for (int i = 0; i < 261; ++i) v = fe_double(v); return v; }();   // 2^256 * 2^261 mod p
+  const F9 c9 = f9_from_fe(scale ? fe_mul(*scale, c) : c);       // fe_mul(s * 2^256, 2^517) = s * 2^517
+  for (int i = 0; i < TW_WORDS; ++i) rec[i] = i < 9 ? c9.l[i] : 0;
 }
 
 int get_plan(plk_ctx* ctx, int log_n, bool inverse, hipStream_t s, NttPlan** out) {
@@ -326,18 +344,6 @@ int get_plan(plk_ctx* ctx, int log_n, bool inverse, hipStream_t s, NttPlan** out
   }
   plan.tab.tw_lo = (const uint32_t*)plan.lo.p;
   plan.tab.tw_hi = (const uint32_t*)plan.hi.p;
-  {
-    // 2^(256+261) mod p as a plain integer: multiplying a raw integer x by it (mont29) gives x * 2^256
-    Fe c = fe_one();
-    for (int i = 0; i < 261; ++i) c = fe_double(c);
-    const F9 c9 = f9_from_fe(c);
-    uint32_t rec[TW_WORDS] = {0};
-    for (int i = 0; i < 9; ++i) rec[i] = c9.l[i];
-    HIP_TRY(ctx, hipMalloc(&plan.from_u64.p, sizeof rec));
-    plan.from_u64.cap = sizeof rec;
-    HIP_TRY(ctx, hipMemcpy(plan.from_u64.p, rec, sizeof rec, hipMemcpyHostToDevice));
-    plan.tab.from_u64 = (const uint32_t*)plan.from_u64.p;
-  }
   plan.tab.tw_hi_scaled = plan.tab.tw_hi;
   plan.tab.scale = nullptr;
   plan.tab.lo_bits = lo_bits;
@@ -384,7 +390,7 @@ int get_plan(plk_ctx* ctx, int log_n, bool inverse, hipStream_t s, NttPlan** out
 // batch <= NTT_MAX_BATCH) or as one base pointer plus a stride in elements.
 int launch_ntt(plk_ctx* ctx, hipStream_t s, const uint64_t* const* in, const uint32_t* kinds, size_t batch,
                size_t n_in, size_t N, bool inverse, uint64_t* const* out, size_t stride_in = 0, size_t stride_out = 0,
-               int cosets = 0, const char* tmp_slot = "ntt_tmp") {
+               int cosets = 0, const char* tmp_slot = "ntt_tmp", const U64Opt* u64opt = nullptr) {
   int log_n, rc;
   if ((rc = check_domain(ctx, N, &log_n))) return rc;
   if (n_in > N) return fail(ctx, PLK_ERR_LENGTH, "more input elements than domain points");
@@ -411,6 +417,9 @@ int launch_ntt(plk_ctx* ctx, hipStream_t s, const uint64_t* const* in, const uin
     prescale = (const uint32_t*)plan->prescale4.p;
   }
 
+  NttU64 u64{};
+  u64_record(u64opt ? u64opt->scale : nullptr, u64.rec);
+  if (u64opt && u64opt->conv_out) { u64.conv_out = u64opt->conv_out; u64.conv_stride = (uint64_t)n_in * 4; u64.conv_first = u64opt->conv_first; }
   NttBatch user{};   // the caller's buffers
   const size_t n_ptr_in = stride_in ? 1 : batch, n_ptr_out = stride_out ? 1 : batch;
   for (size_t b = 0; b < n_ptr_in; ++b) {
@@ -475,6 +484,7 @@ int launch_ntt(plk_ctx* ctx, hipStream_t s, const uint64_t* const* in, const uin
     a.pass = p;
     a.cosets = cosets;
     a.prescale = prescale;
+    a.u64 = u64;
     if (p == 0) from_user(a.batch); else from_tmp(a.batch);
     to_tmp(a.batch);
     // a pass after the first works in place: its tile must pass through LDS between loads and stores,
@@ -503,6 +513,7 @@ int launch_ntt(plk_ctx* ctx, hipStream_t s, const uint64_t* const* in, const uin
     a.cosets = cosets;
     a.prescale = prescale;
     a.coset_stride = (uint64_t)N * 4;
+    a.u64 = u64;
     if (P == 1) from_user(a.batch); else from_tmp(a.batch);
     to_user(a.batch);
     const unsigned tiles = 1u << (log_n - a.log_r - a.log_c);
@@ -848,7 +859,7 @@ int launch_gate_eval(plk_ctx* ctx, hipStream_t s, const uint64_t* const w[4], co
   int ncols = 5;
   for (int k = 0; k < 9; ++k) ncols += cols.s[k] != nullptr;
   {
-  ProfScope ps(ctx, s, "gate_constraint_kernel", 32.0 * ncols * (double)N, 12.0 * (double)N);
+  ProfScope ps(ctx, s, "gate_constraint_kernel", 32.0 * ncols * (double)N, 7.0 * (double)N);
   hipLaunchKernelGGL(gate_constraint_kernel, dim3(blocks), dim3(EW_THREADS), 0, s, cols, (uint64_t)N, out);
   }
   HIP_TRY(ctx, hipGetLastError());
@@ -892,6 +903,9 @@ struct R23Ws {
   uint64_t* col_coef(int c) const { return coef + (size_t)c * n * 4; }
   uint64_t* col_eval(int c) const { return eval + (size_t)c * N * 4; }
   uint64_t* col_cos(int c) const { return eval + (size_t)c * 3 * n * 4; }   // planes 1..3 of column c
+  // coset form (N = 4n) only, behind the 18 columns' planes: beta * F::from(sigma_k[j]), the trace-domain plane of the
+  // scaled sigma columns (r23_sigma_group writes it, r23_perm reads it)
+  uint64_t* sigma_plane0(int k) const { return eval + ((size_t)54 + (size_t)k) * n * 4; }
 };
 
 int r23_workspace(plk_ctx* ctx, size_t n, size_t N, uint64_t* z_out, R23Ws* ws) {
@@ -908,15 +922,25 @@ int r23_workspace(plk_ctx* ctx, size_t n, size_t N, uint64_t* z_out, R23Ws* ws) 
 
 // interpolation of m columns and their three coset transforms, into the workspace columns col_of[b]
 int r23_extend_group(plk_ctx* ctx, hipStream_t s, const R23Ws& ws, const uint64_t* const* cols, const uint32_t* kinds, const int* col_of,
-                     size_t m, const char* tmp_slot = "ntt_tmp") {
+                     size_t m, const char* tmp_slot = "ntt_tmp", const U64Opt* u64opt = nullptr) {
   if (m == 0) return PLK_OK;
   const uint64_t* in[NTT_MAX_BATCH]; uint64_t* out[NTT_MAX_BATCH];
   int rc;
   for (size_t b = 0; b < m; ++b) { in[b] = cols[b]; out[b] = ws.col_coef(col_of[b]); }
-  if ((rc = launch_ntt(ctx, s, in, kinds, m, ws.n, ws.n, true, out, 0, 0, 0, tmp_slot))) return rc;
+  if ((rc = launch_ntt(ctx, s, in, kinds, m, ws.n, ws.n, true, out, 0, 0, 0, tmp_slot, u64opt))) return rc;
   for (size_t b = 0; b < m; ++b) { in[b] = ws.col_coef(col_of[b]); out[b] = ws.col_cos(col_of[b]); }
   return launch_ntt(ctx, s, in, nullptr, m, ws.n, ws.n, false, out, 0, 0, 3, tmp_slot);
 }
+
+// The sigma columns (positions first .. first + 3 of a group, raw indices): in the coset form they are transformed
+// times beta - the permutation check needs beta * sigma_k(x) only, and a constant factor passes through the
+// transforms - with beta * F::from(sigma_k[j]) itself kept as the trace-domain plane.
+struct SigmaScale {
+  Fe beta; U64Opt opt;
+  SigmaScale(const R23Ws& ws, const uint64_t beta_[4], int first) : beta(fe_from_limbs64(beta_)) {
+    opt.scale = &beta; opt.conv_out = ws.sigma_plane0(0); opt.conv_first = first;
+  }
+};
 
 // grand product -> Z interpolation -> Z cosets (column 17)
 int r23_z_chain(plk_ctx* ctx, hipStream_t s, const R23Ws& ws, const uint64_t* const wires[4], const uint64_t* const sigma[4],
@@ -933,7 +957,7 @@ int r23_gate(plk_ctx* ctx, hipStream_t s, const R23Ws& ws, const uint64_t* const
   int ncols = 5;
   for (int k = 0; k < 4; ++k) { g.w0[k] = wires[k]; g.w[k] = ws.col_cos(k); }
   for (int k = 0; k < 9; ++k) { const bool on = sel && sel[k]; g.s0[k] = on ? sel[k] : nullptr; g.s[k] = on ? ws.col_cos(4 + k) : nullptr; ncols += on; }
-  ProfScope ps(ctx, s, "gate_constraint_coset_kernel", 32.0 * ncols * (double)ws.N, 12.0 * (double)ws.N);
+  ProfScope ps(ctx, s, "gate_constraint_coset_kernel", 32.0 * ncols * (double)ws.N, 7.0 * (double)ws.N);
   hipLaunchKernelGGL(gate_constraint_coset_kernel, dim3((unsigned)((ws.N + EW_THREADS - 1) / EW_THREADS)), dim3(EW_THREADS), 0, s, g,
                      (uint64_t)ws.n, gate_out);
   HIP_TRY(ctx, hipGetLastError());
@@ -945,10 +969,11 @@ int r23_perm(plk_ctx* ctx, hipStream_t s, const R23Ws& ws, const uint64_t* const
   const Fe fb = fe_from_limbs64(beta), fg = fe_from_limbs64(gamma);
   PermColsCoset pc{};
   pc.z0 = ws.z; pc.z = ws.col_cos(17);
-  for (int k = 0; k < 4; ++k) { pc.sig0[k] = sigma[k]; pc.sig[k] = ws.col_cos(13 + k); pc.w0[k] = wires[k]; pc.w[k] = ws.col_cos(k); }
-  ProfScope ps(ctx, s, "perm_constraint_coset_kernel", 320.0 * (double)ws.N, 18.0 * (double)ws.N);
+  (void)sigma;   // (its trace-domain plane comes scaled from the workspace)
+  for (int k = 0; k < 4; ++k) { pc.sig0[k] = ws.sigma_plane0(k); pc.sig[k] = ws.col_cos(13 + k); pc.w0[k] = wires[k]; pc.w[k] = ws.col_cos(k); }
+  ProfScope ps(ctx, s, "perm_constraint_coset_kernel", 320.0 * (double)ws.N, 9.0 * (double)ws.N);
   hipLaunchKernelGGL(perm_constraint_coset_kernel, dim3((unsigned)((ws.N + EW_THREADS - 1) / EW_THREADS)), dim3(EW_THREADS), 0, s, pc,
-                     (uint64_t)ws.n, fb, fg, fe_mul(fb, fe_r2()), (uint64_t)(z_shift % ws.N), perm_out);
+                     (uint64_t)ws.n, fg, fe_mul(fb, fe_r2()), (uint64_t)(z_shift % ws.N), perm_out);
   HIP_TRY(ctx, hipGetLastError());
   return PLK_OK;
 }
@@ -992,8 +1017,9 @@ int launch_round23(plk_ctx* ctx, hipStream_t s, const uint64_t* const wires[4], 
     side.record();
     for (int k = 0; k < 4; ++k) { in[m] = wires[k]; kinds[m] = NTT_IN_FIELD; col_of[m] = k; ++m; }
     for (int k = 0; k < 9; ++k) if (sel && sel[k]) { in[m] = sel[k]; kinds[m] = NTT_IN_FIELD; col_of[m] = 4 + k; ++m; }
+    const SigmaScale sg_scale(ws, beta, (int)m);
     for (int k = 0; k < 4; ++k) { in[m] = sigma[k]; kinds[m] = NTT_IN_U64; col_of[m] = 13 + k; ++m; }
-    if ((rc = r23_extend_group(ctx, s, ws, in, kinds, col_of, m))) return rc;
+    if ((rc = r23_extend_group(ctx, s, ws, in, kinds, col_of, m, "ntt_tmp", &sg_scale.opt))) return rc;
     if (gate_out && (rc = r23_gate(ctx, s, ws, wires, sel, gate_out))) return rc;
     side.join();
     if (perm_out && (rc = r23_perm(ctx, s, ws, wires, sigma, beta, gamma, z_shift, perm_out))) return rc;
@@ -1684,7 +1710,8 @@ int round23_host_pipelined(plk_ctx* ctx, const uint64_t* const wires[4], const u
     if (z_out && (rc = get(z_out, dz, (n + 1) * ELEM, EV_Z, false))) return rc;
     const uint32_t kinds[4] = {NTT_IN_U64, NTT_IN_U64, NTT_IN_U64, NTT_IN_U64};
     const int col_of[4] = {13, 14, 15, 16};
-    if ((rc = r23_extend_group(ctx, s, ws, sg, kinds, col_of, 4))) return rc;
+    const SigmaScale sg_scale(ws, beta, 0);
+    if ((rc = r23_extend_group(ctx, s, ws, sg, kinds, col_of, 4, "ntt_tmp", &sg_scale.opt))) return rc;
     side.join();
   }
   if (perm_out) {

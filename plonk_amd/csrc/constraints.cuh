@@ -25,26 +25,40 @@ struct GateCols {
 // bounds are beside each line, in units of p; inputs are canonical, below p).
 __device__ __forceinline__ F9 f9_load(const uint64_t* col, uint64_t i) { return f9_from_fe(fe_load(col, i)); }
 
+// The sum is regrouped by wire so that it costs seven products instead of the eleven of the term-by-term form
+// (field arithmetic is exact, so the value is the same element):
+//   G = o (s_Add + s_Sub + s_Not + s_Mult + s_If + b s_Div + (a - b) s_Eq)
+//     - a (s_Add + s_Sub - s_Not + s_Div + b (s_Mult + s_If) - c s_If)
+//     - b (s_Add - s_Sub) - s_Not - c s_If.
+// Int (0) and Bool (1) contribute F::zero() (:396-397).  An absent selector is a zero column.
 __device__ __forceinline__ Fe gate_point(const F9& a, const F9& b, const F9& c, const F9& o, const uint64_t* const s[9], uint64_t i) {
-  const F9 one = f9_from_fe(fe_one());
-  F9 acc;
+  F9 zero;
 #pragma unroll
-  for (int k = 0; k < 9; ++k) acc.l[k] = 0;
-  // Int (0) and Bool (1) contribute F::zero() (:396-397)
-  if (s[2]) acc = f9_add(acc, mont256(f9_sub_q4(o, f9_add(a, b)), f9_load(s[2], i)));                   // Add  :400   o-(a+b) < 5, term < 3.3
-  if (s[3]) acc = f9_add(acc, mont256(f9_add(f9_sub_q2(o, a), b), f9_load(s[3], i)));                   // Sub  :403   o-a+b < 4, term < 2.9
-  if (s[4] || s[8]) {
-    const F9 ab = mont256(a, b);                                                                        // < 1.46
-    if (s[4]) acc = f9_add(acc, mont256(f9_sub_q2(o, ab), f9_load(s[4], i)));                           // Mult :406   < 3, term < 2.4
-    if (s[8]) {                                                                                         // If   :419-423
-      const F9 t = mont256(f9_sub_q2(one, a), c);                                                       // (1-a) c < 2.4
-      acc = f9_add(acc, mont256(f9_sub_q4(o, f9_add(ab, t)), f9_load(s[8], i)));                        // ab + t < 3.9; < 5, term < 3.3
-    }
-  }
-  if (s[5]) acc = f9_add(acc, mont256(f9_sub_q2(mont256(o, b), a), f9_load(s[5], i)));                  // Div  :409   o b - a < 3.5, term < 2.6
-  if (s[6]) acc = f9_add(acc, mont256(mont256(f9_sub_q2(a, b), o), f9_load(s[6], i)));                  // Eq   :412   (a-b) o < 2.4, term < 2.1
-  if (s[7]) acc = f9_add(acc, mont256(f9_add(o, f9_sub_q2(a, one)), f9_load(s[7], i)));                 // Not  :415   o+a-1 < 4, term < 2.9
-  return fe_reduce_f9(acc);       // seven terms: limbs below 7 * 2^29, value below 20 p
+  for (int k = 0; k < 9; ++k) zero.l[k] = 0;
+  const F9 s_add = s[2] ? f9_load(s[2], i) : zero, s_sub = s[3] ? f9_load(s[3], i) : zero, s_mul = s[4] ? f9_load(s[4], i) : zero;
+  const F9 s_div = s[5] ? f9_load(s[5], i) : zero, s_eq = s[6] ? f9_load(s[6], i) : zero, s_not = s[7] ? f9_load(s[7], i) : zero;
+  const F9 s_if = s[8] ? f9_load(s[8], i) : zero;
+  const F9 addsub = f9_add(s_add, s_sub);                                           // < 2, limbs < 2 * 2^29
+  // coefficient of o:                                                                 value (units of p), limbs (units of 2^29)
+  F9 co = f9_add(f9_add(addsub, s_not), f9_add(s_mul, s_if));                       // < 5, < 5
+  if (s[5]) co = f9_add(co, mont256(b, s_div));                                     // + 1.46 -> < 6.5, < 6
+  if (s[6]) co = f9_add(co, mont256(f9_sub_q2(a, b), s_eq));                        // a - b + 2p < 3: + 2.36 -> < 8.9, < 7
+  f9_normalize(co);
+  const F9 po = mont256(o, co);                                                     // < 0.4527 * 8.9 + 1 = 5.1
+  // coefficient of a: s_Add + s_Sub + s_Div + b (s_Mult + s_If) + 4p - (s_Not + c s_If)
+  F9 neg = s_not;                                                                   // what the sum subtracts: starts at s_Not
+  F9 ca = f9_add(addsub, s_div);                                                    // < 3, < 3
+  if (s[4] || s[8]) ca = f9_add(ca, mont256(f9_add(s_mul, s_if), b));               // + 1.91 -> < 4.91, < 4
+  F9 cif = zero;
+  if (s[8]) { cif = mont256(c, s_if); neg = f9_add(neg, cif); }                     // c s_If < 1.46; s_Not + c s_If < 2.46, limbs < 2
+  ca = f9_sub_q4(ca, neg);                                                          // < 8.91, limbs < 4 + 3 = 7
+  f9_normalize(ca);
+  const F9 pa = mont256(a, ca);                                                     // < 0.4527 * 8.91 + 1 = 5.1
+  // G = po + 16p - (pa + b (s_Add - s_Sub) + s_Not + c s_If)
+  F9 sub = f9_add(pa, neg);                                                         // < 5.1 + 2.46 = 7.6, limbs < 3
+  if (s[2] || s[3]) sub = f9_add(sub, mont256(f9_sub_q2(s_add, s_sub), b));         // (s_Add - s_Sub + 2p) b < 2.36 -> < 9.9, limbs < 4
+  f9_normalize(sub);
+  return fe_reduce_f9(f9_sub_k<16>(po, sub));                                       // < 5.1 + 16 = 21.1 < 32
 }
 
 __global__ __launch_bounds__(EW_THREADS) void gate_constraint_kernel(GateCols cols, uint64_t N, uint64_t* out) {
@@ -100,17 +114,26 @@ struct PermPoint {
     if (j == 0) { f9_normalize(tl); f9_normalize(tr); lhs = tl; rhs = tr; }
     else { lhs = mont256(tl, lhs); rhs = mont256(tr, rhs); }   // < 6.5, 11.2, 18.5
   }
+  // the same with beta * sigma(point) already at hand (a canonical element): no product for the term
+  __host__ __device__ __forceinline__ void wire_scaled(int j, const F9& w, const F9& beta_sigma) {
+    F9 tl = f9_add(w, bi_g);                                  // < 3.5, limbs < 3 * 2^29
+    F9 tr = f9_add(f9_add(w, beta_sigma), gamma);             // < 3
+    if (j == 0) { f9_normalize(tl); f9_normalize(tr); lhs = tl; rhs = tr; }
+    else { lhs = mont256(tl, lhs); rhs = mont256(tr, rhs); }   // < 6.5, 11.2, 18.5
+  }
   __host__ __device__ __forceinline__ Fe finish(const F9& z_next, const F9& z_cur) const {
     return fe_reduce_f9(f9_sub_k<16>(mont256(lhs, z_next), mont256(rhs, z_cur)));   // each < 9.4; difference + 16 p < 26
   }
 };
 
+// Every sigma plane holds beta * sigma_k at its points (the columns were transformed times beta; plane 0 is
+// beta * F::from(sigma_k[j]), written by the interpolation's first pass), so a wire's right-hand term costs no product.
 struct PermColsCoset {
-  const uint64_t* z0;  const uint64_t* sig0[4];  const uint64_t* w0[4];   // plane 0: z[0..n), RAW u64 sigma indices, wire table
+  const uint64_t* z0;  const uint64_t* sig0[4];  const uint64_t* w0[4];   // plane 0: z[0..n), beta * sigma, wire table
   const uint64_t* z;   const uint64_t* sig[4];   const uint64_t* w[4];    // planes 1..3
 };
 
-__global__ __launch_bounds__(EW_THREADS) void perm_constraint_coset_kernel(PermColsCoset cols, uint64_t n, Fe beta, Fe gamma, Fe beta_r2,
+__global__ __launch_bounds__(EW_THREADS) void perm_constraint_coset_kernel(PermColsCoset cols, uint64_t n, Fe gamma, Fe beta_r2,
                                                                            uint64_t z_shift, uint64_t* out) {
   const uint64_t i = (uint64_t)blockIdx.x * EW_THREADS + threadIdx.x;
   const uint64_t N = 4 * n;
@@ -122,15 +145,8 @@ __global__ __launch_bounds__(EW_THREADS) void perm_constraint_coset_kernel(PermC
   const uint64_t rn = inext & 3, kn = inext >> 2;
   const uint64_t off = r ? (uint64_t)(r - 1) * n * 4 : 0;
   PermPoint pt(i, beta_r2, gamma);
-  // on the trace domain sigma_j(omega^k) IS F::from(sigma_j[k]): the raw index times beta * R^2;
-  // elsewhere the evaluated sigma polynomial times beta.  One multiplication either way.
-  const F9 y = f9_from_fe(r ? beta : beta_r2);
   auto wire = [&](int j) {          // called four times in so many words: the loop form is not unrolled (the products hold asm statements)
-    const F9 w = f9_load(r ? cols.w[j] + off : cols.w0[j], k);
-    F9 x;
-    if (r) x = f9_load(cols.sig[j] + off, k);
-    else x = f9_from_u64(cols.sig0[j][k]);
-    pt.wire(j, w, x, y);
+    pt.wire_scaled(j, f9_load(r ? cols.w[j] + off : cols.w0[j], k), f9_load(r ? cols.sig[j] + off : cols.sig0[j], k));
   };
   wire(0); wire(1); wire(2); wire(3);
   // (z is read last: fewer values are alive across the products above)

@@ -25,6 +25,7 @@
 
 namespace plk {
 
+constexpr int TW_WORDS = 12;                // one twiddle record (9 limbs + padding)
 constexpr int NTT_TILE_LOG = 11;            // elements per workgroup tile
 constexpr int NTT_TILE = 1 << NTT_TILE_LOG;
 constexpr int NTT_THREADS = 512;
@@ -34,7 +35,6 @@ constexpr int NTT_LDS_TW_LOG = 7;           // per-tile twiddles kept in LDS whe
 constexpr int NTT_LDS_TW_RECORDS = 192;     // the LDS twiddle area (tile_transform says how each radix fills it)
 constexpr size_t NTT_LDS_BYTES = ((size_t)NTT_TILE + NTT_LDS_TW_RECORDS) * 36;   // 9 words per element; 2 workgroups per CU
 static_assert(2 * ((NTT_LDS_BYTES + 511) / 512 * 512) <= 160 * 1024, "two workgroups of the transform kernels share a CU's LDS");
-constexpr int TW_WORDS = 12;                // one twiddle record (9 limbs + padding)
 
 enum NttInputKind : uint32_t { NTT_IN_FIELD = 0, NTT_IN_U64 = 1 };
 
@@ -61,7 +61,6 @@ struct NttTables {
   const uint32_t* tw_hi_scaled;  // same times 1/N (inverse, first inter-pass twiddle); == tw_hi for forward
   const uint32_t* tw_lo;   // omega_N^e, e < 2^lo_bits
   const uint32_t* scale;   // 1/N as one record, or nullptr
-  const uint32_t* from_u64;  // 2^(256+261) mod p: raw integer -> element, one record
   // full inter-pass tables (nullptr = use the two-level pair above): after pass p,
   // record[(k << log_inner) + q] = omega_{N'}^(k q), times 1/N in pass 0 of an inverse transform
   const uint32_t* tw_full[2];
@@ -90,8 +89,21 @@ struct Tile {
   }
 };
 
+// What a launch does with columns of raw 64-bit integers (NTT_IN_U64), passed by value with the kernel arguments.
+struct NttU64 {
+  // the conversion constant as a twiddle record: 2^(256+261) mod p turns the integer x into the element F::from(x);
+  // c * 2^(256+261) mod p turns it into c * F::from(x) (a caller that wants c times the column transformed: the
+  // transforms are linear)
+  uint32_t rec[TW_WORDS];
+  // where the converted inputs go as canonical elements (column b at conv_out + (b - conv_first) * conv_stride
+  // uint64_t units), or nullptr
+  uint64_t* conv_out;
+  uint64_t conv_stride;
+  int conv_first;
+};
+
 // One input element -> normalised F9 (value < 1.5 p).
-__device__ __forceinline__ F9 load_input(const uint64_t* in, uint64_t idx, bool valid, uint32_t kind, const uint32_t* from_u64) {
+__device__ __forceinline__ F9 load_input(const uint64_t* in, uint64_t idx, bool valid, uint32_t kind, const NttU64& u64) {
   F9 v;
   if (!valid) {
 #pragma unroll
@@ -101,7 +113,10 @@ __device__ __forceinline__ F9 load_input(const uint64_t* in, uint64_t idx, bool 
 #pragma unroll
     for (int i = 0; i < 9; ++i) v.l[i] = 0;
     v.l[0] = (uint32_t)x & M29; v.l[1] = (uint32_t)(x >> 29) & M29; v.l[2] = (uint32_t)(x >> 58);
-    v = mont29(v, f9_load_tw(from_u64, 0));   // F::from(u64)
+    F9 c;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) c.l[i] = u64.rec[i];
+    v = mont29(v, c);   // F::from(u64), times the caller's constant if there is one
   } else {
     v = f9_from_fe(fe_load(in, idx));
   }
@@ -305,6 +320,7 @@ struct NttPassArgs {
   int cosets;
   const uint32_t* prescale;
   uint32_t slots;    // transforms in this launch; the grid is 1-D with tiles * slots workgroups
+  NttU64 u64;        // first pass only
 };
 
 // Non-final pass: digit transform + inter-pass twiddle; out may alias in when !first.
@@ -344,7 +360,9 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void ntt_pass_kernel(const NttPassA
   auto load =
       [&](int r, int c) {   // row r of the digit this pass transforms: a run of 2^log_c consecutive elements per row
         const uint64_t idx = base + ((uint64_t)r << log_inner) + c;
-        F9 v = load_input(in, idx, !(a.first && idx >= a.n_in), kind, a.tab.from_u64);
+        const bool valid = !(a.first && idx >= a.n_in);
+        F9 v = load_input(in, idx, valid, kind, a.u64);
+        if (kind == NTT_IN_U64 && a.u64.conv_out && valid) fe_store(a.u64.conv_out + (uint64_t)(poly - a.u64.conv_first) * a.u64.conv_stride, idx, fe_reduce_f9(v));
         if (a.first && a.cosets) v = mont29(v, f9_load_tw(a.prescale, ((uint64_t)coset << a.log_n) + idx));
         return v;
       };
@@ -372,6 +390,7 @@ struct NttFinalArgs {
   int cosets;
   const uint32_t* prescale;
   uint64_t coset_stride;   // in uint64_t units
+  NttU64 u64;              // when this is the only pass
 };
 
 // Last pass: contiguous rows in, natural-order scatter out (never in place), canonical values.
@@ -400,7 +419,9 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void ntt_final_kernel(const NttFina
       [&](int r, int c) {
         const uint64_t orow = ((k1_0 + c) << a.log_r2) + k2;
         const uint64_t idx = (orow << log_r) + r;
-        F9 v = load_input(in, idx, !(a.first && idx >= a.n_in), kind, a.tab.from_u64);
+        const bool valid = !(a.first && idx >= a.n_in);
+        F9 v = load_input(in, idx, valid, kind, a.u64);
+        if (kind == NTT_IN_U64 && a.u64.conv_out && valid) fe_store(a.u64.conv_out + (uint64_t)(poly - a.u64.conv_first) * a.u64.conv_stride, idx, fe_reduce_f9(v));
         if (a.first && a.cosets) v = mont29(v, f9_load_tw(a.prescale, ((uint64_t)(slot % a.cosets) << a.log_n) + idx));
         return v;
       };
