@@ -139,7 +139,7 @@ __device__ __forceinline__ F9 load_input(const uint64_t* in, uint64_t idx, bool 
 // SH = true: the butterfly products of the later steps use the precomputed-quotient form (shoup29_x2, 143
 // multiply-adds instead of 153) with twiddle pairs (w, wq) from `master_sh` kept in the LDS twiddle area.
 //   radix <= 2^7:  the area holds the radix's whole table as pairs (at most 64: records 0-63 w, 64-127 wq);
-//   radix >= 2^9:  32 pairs (records 0-31 w, 32-63 wq) serve the steps up to h = 16 (omega_{4h}^x with 4h <= 64 is a
+//   radix >= 2^8:  32 pairs (records 0-31 w, 32-63 wq) serve the steps up to h = 16 (omega_{4h}^x with 4h <= 64 is a
 //                  power of omega_64 whatever the radix), 128 plain twiddles (records 64-191, the powers of
 //                  omega_256) serve the step h = 64, and the steps beyond take plain twiddles from memory.
 // Same values, same bounds (both products return < 1.91 p).  See ntt_use_sh for who picks it.
@@ -165,7 +165,7 @@ __device__ __forceinline__ void tile_transform(const Tile& t, int log_r, int log
   const Tile ltw(reinterpret_cast<unsigned char*>(t.A) + (size_t)NTT_TILE * 36, NTT_LDS_TW_RECORDS);
   const bool tw_lds = log_r - 1 <= NTT_LDS_TW_LOG;
   static_assert(SH || !BIG, "BIG is a form of SH");
-  constexpr bool big = BIG;                                  // radix >= 2^9
+  constexpr bool big = BIG;                                  // radix >= 2^8
   constexpr int SH_SLOTS = big ? 32 : 64;                    // pairs in the LDS twiddle area
   const int sh_shift = big ? log_r - 6 : 0;                  // radix index -> index into the pairs (powers of omega_64)
   constexpr int MID_BASE = 64, MID_LOG = 8;                  // big: plain powers of omega_256 behind the pairs
@@ -283,9 +283,11 @@ __device__ __forceinline__ void tile_transform(const Tile& t, int log_r, int log
 }
 
 // Which form a pass of radix 2^log_r takes: pairs in LDS for every step (radix <= 2^7) or for the steps that fit
-// (radix >= 2^9, the rest from LDS and memory as plain twiddles: BIG, a kernel instantiation of its own, so that the
-// common radices keep their register budget); a radix of 2^8 keeps its 128 plain twiddles in LDS.
-__host__ __device__ __forceinline__ bool ntt_big_radix(const uint32_t* master_sh, int log_r) { return master_sh && log_r >= NTT_LDS_TW_LOG + 2; }
+// (radix >= 2^8, the rest from LDS and memory as plain twiddles: BIG, a kernel instantiation of its own, so that the
+// common radices keep their register budget; for the radix 2^8 itself that is the steps h = 4 and h = 16 on pairs and
+// the step h = 64 on its 128 plain twiddles: direct transforms of 2^22 and 2^24 points 1.5-2 % faster than with
+// plain twiddles throughout).
+__host__ __device__ __forceinline__ bool ntt_big_radix(const uint32_t* master_sh, int log_r) { return master_sh && log_r >= NTT_LDS_TW_LOG + 1; }
 
 template <bool BIG, class Load, class Store>
 __device__ __forceinline__ void tile_transform_any(const Tile& t, int log_r, int log_c, const uint32_t* master, const uint32_t* master_sh,
