@@ -199,3 +199,30 @@ def test_pointwise_kernels_at_extreme_values(prover):
                 lhs = lhs * (wires[k][i] + beta * i + gamma) % p
                 rhs = rhs * (wires[k][i] + beta * sigma[k][i] + gamma) % p
             assert got[i] == (z[(i + shift) % N] * lhs - z[i] * rhs) % p, ("perm", shift, i)
+
+
+@pytest.mark.parametrize("log_n,kinds", [(3, pa.AST_KINDS), (8, pa.AST_KINDS), (8, ("Add", "Div", "If")), (12, ("Sub", "Mult", "Eq", "Not"))])
+def test_round23_at_extreme_values(ctx, log_n, kinds):
+    """Rounds 2+3 on the 4n-point domain (the coset-major kernels: gate sum regrouped by wire, sigma columns carried
+    times beta through their transforms) with wire and selector columns made of 0, 1, 2, p - 1, p - 2, p - 3,
+    (p - 1) / 2 and random elements, selectors that are not 0/1 included, against the CPU oracle."""
+    n = 1 << log_n
+    p = synth.P_INT
+    special = [0, 1, p - 1, p - 2, (p - 1) // 2, 2, p - 3]
+    rng = np.random.default_rng(100 + log_n)
+
+    def column(period, phase):
+        vals = []
+        for i in range(n):
+            k = (i // period + phase) % (len(special) + 2)
+            vals.append(special[k] if k < len(special) else int(rng.integers(0, 1 << 62)) ** 5 % p)
+        return synth.ints_to_mont(vals)
+
+    c = synth.make_circuit(n, circuit_id=40 + log_n, kinds=kinds)
+    c.table.input1, c.table.input2, c.table.input3, c.table.output = column(1, 0), column(2, 3), column(5, 5), column(3, 1)
+    for j, k in enumerate(sorted(c.table.selectors)):
+        if j % 2 == 0:
+            c.table.selectors[k] = column(4, j)
+    z, g, e = pa.prove_round23(c.table, c.perm, c.beta, c.gamma, D(n), D(4 * n), ctx=ctx)
+    zr, gr, er = co.round23(c.table.wires(), c.table.selectors, c.perm.columns(), 4 * n, c.beta, c.gamma)
+    assert same(z, zr) and same(g, gr) and same(e, er)
