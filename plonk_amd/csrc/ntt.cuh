@@ -413,9 +413,8 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void ntt_final_kernel(const NttFina
   const uint64_t k1_0 = (uint64_t)(blockIdx.x >> a.log_r2) << log_c;
   const uint32_t kind = a.first ? a.batch.kind_of(poly) : (uint32_t)NTT_IN_FIELD;
 
-  const bool scaled = a.tab.scale != nullptr;
-  F9 sc;
-  if (scaled) sc = f9_load_tw(a.tab.scale, 0);
+  const bool scaled = a.tab.scale != nullptr;   // single-pass inverse transforms only: the record is read where it is used, so that
+                                               // the larger transforms do not hold nine registers for it across the tile transform
   const bool quarter = a.first && log_r >= 2 && (a.n_in << 2) <= (1ull << a.log_n);
   auto load =
       [&](int r, int c) {
@@ -430,7 +429,7 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void ntt_final_kernel(const NttFina
   auto store =
       [&](int k, int c, const F9& v) {
         const uint64_t dst = (k1_0 + c) + (k2 << a.log_r1) + ((uint64_t)k << (a.log_r1 + a.log_r2));
-        fe_store(out, dst, fe_reduce_f9(scaled ? mont29(v, sc) : v));
+        fe_store(out, dst, fe_reduce_f9(scaled ? mont29(v, f9_load_tw(a.tab.scale, 0)) : v));
       };
   tile_transform_any<BIG>(tile, log_r, log_c, a.tab.master, a.tab.master_sh, quarter, load, store);
 }
