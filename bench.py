@@ -51,6 +51,8 @@ def parse_args():
     ap.add_argument("--cpu-sample-log-n", type=int, default=20,
                     help="rows of the CPU-baseline run (log2); below --log-n the time is scaled by the row count")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-four-step", action="store_true", help="multi-GPU runs: leave the sharded 2^24-point transform out")
+    ap.add_argument("--four-step-limit", type=int, default=120, help="seconds the sharded transform may take before the line goes out without it")
     ap.add_argument("--no-profile", action="store_true", help="time the steps without the per-launch events (no roofline object)")
     ap.add_argument("--no-lean-variant", action="store_true",
                     help="skip the extra figure without the Int/Bool selector columns (a profiler run wants one launch shape per kernel)")
@@ -299,6 +301,56 @@ def other_workloads(args, prover, dist, rank, world):
         dist.destroy_process_group()
 
 
+def four_step_extra(prover, dist, world, device, log_N=24, steps=5, warmup=2):
+    """Not part of `value`: ONE transform of 2^24 points sharded contiguously over the ranks (four-step form, three
+    all-to-all exchanges over RCCL), timed like the main region, plus a forward-then-inverse round trip that must give
+    the input back bit for bit - which checks the exchanges and their ordering against the library's kernels on
+    whatever links the ranks really have.  Every rank calls this; the dictionary is the same on all of them."""
+    import torch
+    from plonk_amd import dist as pdist
+    N = 1 << log_N
+    m = N // world
+    g = torch.Generator(device=device)
+    g.manual_seed(1234 + (dist.get_rank() if dist is not None else 0))
+    # canonical elements: three random low limbs and a top limb below 2^62 (value < 2^254 < p)
+    x = torch.randint(-(1 << 63), (1 << 63) - 1, (m, 4), dtype=torch.int64, device=device, generator=g)
+    x[:, 3] = x[:, 3] & ((1 << 62) - 1)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed_ms(fn):
+        for _ in range(warmup):
+            fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt * 1e3 / steps
+
+    y = pdist.four_step_ntt(x, N, prover)
+    back = pdist.four_step_ntt(y, N, prover, inverse=True)
+    ok = torch.tensor([1 if torch.equal(back, x) else 0], dtype=torch.int64, device=device)
+    if dist is not None:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    ms = timed_ms(lambda: pdist.four_step_ntt(x, N, prover))
+    ms_t = timed_ms(lambda: pdist.four_step_ntt(x, N, prover, natural_output=False))
+    return {"what": f"one transform of N=2^{log_N} points sharded contiguously over {world} GPU(s), natural order in and out: "
+                    f"three all-to-all exchanges of {(world - 1) * N // (world * world) * 32 / 2**20:.1f} MiB per GPU each",
+            "ms": round(ms, 4), "gelem_per_s": round(N / (ms * 1e-3) / 1e9, 3),
+            "frac_of_hbm_roofline": round(N / (ms * 1e-3) / 1e9 / NTT_ROOFLINE_GELEM, 4),
+            "transposed_output_ms": round(ms_t, 4), "round_trip_bit_exact": bool(int(ok.item())), "steps": steps, "scaling": "strong"}
+
+
 def main():
     args = parse_args()
     import torch
@@ -444,6 +496,32 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.log_n, args.blowup, min(args.cpu_sample_log_n, args.log_n))
+    else:
+        line = None
+
+    # Extra figure of a multi-GPU run, after the timed region and outside `value`: the sharded 2^24-point transform,
+    # the one shape of this path with a real exchange step.  A watchdog bounds it: if the exchanges do not finish in
+    # time the line goes out without the figure and the ranks leave, so the headline measurement cannot be lost to it.
+    if world > 1 and not args.no_four_step:
+        import threading
+        done = threading.Event()
+
+        def watchdog():
+            if not done.wait(args.four_step_limit):
+                if rank == 0:
+                    line["four_step"] = {"error": f"did not finish within {args.four_step_limit} s"}
+                    print(json.dumps(line), flush=True)
+                os._exit(0)
+
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            extra = four_step_extra(prover, dist, world, prover.device)
+        except Exception as e:   # noqa: BLE001 - whatever the exchange raised, the main figure still goes out
+            extra = {"error": f"{type(e).__name__}: {e}"[:300]}
+        done.set()
+        if rank == 0:
+            line["four_step"] = extra
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
