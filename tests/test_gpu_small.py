@@ -111,3 +111,20 @@ def test_failures_are_reported_with_their_row(prover, log_n, row):
     prover.round23(dc, N, out=out)
     prover.status()
     assert _same(out, _oracle(c, N, c.beta, c.gamma))
+
+
+def test_randomised_sweep(prover):
+    """Thirty random cases of the device-resident call: sizes 2^2 .. 2^13, any subset of the selector kinds, the
+    4n-point domain mostly (the coset-major kernels) and n, 2n, 8n now and then (the natural-order ones), any z_shift."""
+    from plonk_amd.api import AST_KINDS
+    rng = np.random.default_rng(2024)
+    for case in range(30):
+        log_n = int(rng.integers(2, 14))
+        n = 1 << log_n
+        N = n * (4 if rng.random() < 0.75 else int(rng.choice([1, 2, 8])))
+        kinds = tuple(k for k in AST_KINDS if rng.random() < 0.6)
+        z_shift = int(rng.choice([1, 1, 4, 3, N - 1, int(rng.integers(0, N))]))
+        c = synth.make_circuit(n, circuit_id=int(rng.integers(0, 1 << 20)), kinds=kinds)
+        outs = prover.round23(prover.upload(c), N, z_shift=z_shift)
+        prover.status()
+        assert _same(outs, _oracle(c, N, c.beta, c.gamma, z_shift=z_shift)), (case, log_n, N // n, kinds, z_shift)
