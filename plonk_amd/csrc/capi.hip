@@ -40,6 +40,10 @@ struct GpScratch {
 };
 
 
+#ifndef PLK_FIXED_RADIX
+#define PLK_FIXED_RADIX 1
+#endif
+
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
@@ -496,7 +500,13 @@ int launch_ntt(plk_ctx* ctx, hipStream_t s, const uint64_t* const* in, const uin
     // + the inter-pass twiddle (two products through the two-level table), + the coset prescale in the first pass
     const double per_elem = tile_products(lr, p == 0 && quarter_in) + (plan->tab.tw_full[p] ? 1.0 : 2.0) + ((p == 0 && cosets) ? 1.0 : 0.0);
     ProfScope ps(ctx, s, "ntt_pass_kernel" + tag + "/p" + std::to_string(p), alg_share, per_elem * elems + (p == 0 ? u64_products : 0.0));
-    if (ntt_big_radix(plan->tab.master_sh, lr)) hipLaunchKernelGGL(ntt_pass_kernel<true>, dim3((unsigned)(tiles * slots)), dim3(NTT_THREADS), lds_bytes, s, a);
+    // full tiles of the large radices take the instantiation with the radix fixed at compile time (steps unrolled, each
+    // with its one product form: the non-final passes of the 2^20-point plans 1.5 % faster, the direct 2^24-point transform 2 %)
+    const bool fixed = PLK_FIXED_RADIX && ntt_big_radix(plan->tab.master_sh, lr) && a.log_c == NTT_TILE_LOG - lr;
+    if (fixed && lr == 10) hipLaunchKernelGGL((ntt_pass_kernel<true, 10>), dim3((unsigned)(tiles * slots)), dim3(NTT_THREADS), lds_bytes, s, a);
+    else if (fixed && lr == 9) hipLaunchKernelGGL((ntt_pass_kernel<true, 9>), dim3((unsigned)(tiles * slots)), dim3(NTT_THREADS), lds_bytes, s, a);
+    else if (fixed && lr == 8) hipLaunchKernelGGL((ntt_pass_kernel<true, 8>), dim3((unsigned)(tiles * slots)), dim3(NTT_THREADS), lds_bytes, s, a);
+    else if (ntt_big_radix(plan->tab.master_sh, lr)) hipLaunchKernelGGL(ntt_pass_kernel<true>, dim3((unsigned)(tiles * slots)), dim3(NTT_THREADS), lds_bytes, s, a);
     else hipLaunchKernelGGL(ntt_pass_kernel<false>, dim3((unsigned)(tiles * slots)), dim3(NTT_THREADS), lds_bytes, s, a);
     HIP_TRY(ctx, hipGetLastError());
   }
@@ -519,6 +529,7 @@ int launch_ntt(plk_ctx* ctx, hipStream_t s, const uint64_t* const* in, const uin
     const unsigned tiles = 1u << (log_n - a.log_r - a.log_c);
     const double per_elem = tile_products(a.log_r, P == 1 && quarter_in) + (plan->tab.scale ? 1.0 : 0.0) + ((P == 1 && cosets) ? 1.0 : 0.0);
     ProfScope ps(ctx, s, "ntt_final_kernel" + tag, alg_share, per_elem * elems + (P == 1 ? u64_products : 0.0));
+    // (the last pass keeps the run-time radix: its fixed-radix instantiation was measured 3 % slower)
     if (ntt_big_radix(plan->tab.master_sh, a.log_r)) hipLaunchKernelGGL(ntt_final_kernel<true>, dim3(tiles, (unsigned)slots), dim3(NTT_THREADS), lds_bytes, s, a);
     else hipLaunchKernelGGL(ntt_final_kernel<false>, dim3(tiles, (unsigned)slots), dim3(NTT_THREADS), lds_bytes, s, a);
     HIP_TRY(ctx, hipGetLastError());

@@ -144,9 +144,12 @@ __device__ __forceinline__ F9 load_input(const uint64_t* in, uint64_t idx, bool 
 //                  omega_256) serve the step h = 64, and the steps beyond take plain twiddles from memory.
 // Same values, same bounds (both products return < 1.91 p).  See ntt_use_sh for who picks it.
 struct TwPair { F9 w, q; };
-template <bool SH, bool BIG, class Load, class Store>
-__device__ __forceinline__ void tile_transform(const Tile& t, int log_r, int log_c, const uint32_t* master, const uint32_t* master_sh,
+// LR != 0: the radix is the compile-time constant 2^LR and the tile is full (2^(NTT_TILE_LOG - LR) columns): the steps
+// are unrolled, each with the one product form it takes and its index arithmetic folded into constants.
+template <bool SH, bool BIG, int LR, class Load, class Store>
+__device__ __forceinline__ void tile_transform(const Tile& t, int log_r_arg, int log_c_arg, const uint32_t* master, const uint32_t* master_sh,
                                                bool quarter, Load load, Store store) {
+  const int log_r = LR ? LR : log_r_arg, log_c = LR ? NTT_TILE_LOG - LR : log_c_arg;
   const int cmask = (1 << log_c) - 1;
   if (log_r == 0) {
     for (int c = threadIdx.x; c <= cmask; c += NTT_THREADS) store(0, c, load(0, c));
@@ -219,8 +222,7 @@ __device__ __forceinline__ void tile_transform(const Tile& t, int log_r, int log
     __syncthreads();
   }
 
-  int lh = 2;
-  for (; lh + 1 < log_r; lh += 2) {   // two stages per step
+  auto paired_step = [&](const int lh) __attribute__((always_inline)) {   // two stages per step
     const int h = 1 << lh;
     const bool last = lh + 2 == log_r;
     const bool sh = SH && 2 * h <= SH_SLOTS;              // this step's twiddles are among the pairs
@@ -249,8 +251,22 @@ __device__ __forceinline__ void tile_transform(const Tile& t, int log_r, int log
       if (last) { store(i0, c, y0); store(i0 + h, c, y1); store(i0 + 2 * h, c, y2); store(i0 + 3 * h, c, y3); }
       else { t.put(e0, y0); t.put(e0 + step, y1); t.put(e0 + 2 * step, y2); t.put(e0 + 3 * step, y3); }
     }
-    if (last) return;
-    __syncthreads();
+  };
+  int lh = 2;
+  if constexpr (LR != 0) {
+#pragma unroll
+    for (int l = 2; l + 1 < LR; l += 2) {
+      paired_step(l);
+      if (l + 2 == LR) return;
+      __syncthreads();
+    }
+    lh = 2 + 2 * ((LR - 2) / 2);
+  } else {
+    for (; lh + 1 < log_r; lh += 2) {
+      paired_step(lh);
+      if (lh + 2 == log_r) return;
+      __syncthreads();
+    }
   }
 
   {  // one stage left (lh = log_r - 1): two butterflies per thread, their products interleaved
@@ -289,12 +305,13 @@ __device__ __forceinline__ void tile_transform(const Tile& t, int log_r, int log
 // plain twiddles throughout).
 __host__ __device__ __forceinline__ bool ntt_big_radix(const uint32_t* master_sh, int log_r) { return master_sh && log_r >= NTT_LDS_TW_LOG + 1; }
 
-template <bool BIG, class Load, class Store>
+template <bool BIG, int LR = 0, class Load, class Store>
 __device__ __forceinline__ void tile_transform_any(const Tile& t, int log_r, int log_c, const uint32_t* master, const uint32_t* master_sh,
                                                    bool quarter, Load load, Store store) {
-  if constexpr (BIG) tile_transform<true, true>(t, log_r, log_c, master, master_sh, quarter, load, store);
-  else if (master_sh && log_r >= 3 && log_r <= NTT_LDS_TW_LOG) tile_transform<true, false>(t, log_r, log_c, master, master_sh, quarter, load, store);
-  else tile_transform<false, false>(t, log_r, log_c, master, master_sh, quarter, load, store);
+  static_assert(LR == 0 || (BIG && LR > NTT_LDS_TW_LOG), "the fixed-radix form is instantiated for large radices only");
+  if constexpr (BIG) tile_transform<true, true, LR>(t, log_r, log_c, master, master_sh, quarter, load, store);
+  else if (master_sh && log_r >= 3 && log_r <= NTT_LDS_TW_LOG) tile_transform<true, false, 0>(t, log_r, log_c, master, master_sh, quarter, load, store);
+  else tile_transform<false, false, 0>(t, log_r, log_c, master, master_sh, quarter, load, store);
 }
 
 // omega_N^E (twiddle record) from the two-level table
@@ -333,7 +350,7 @@ struct NttPassArgs {
 // cosets) run on one XCD at about the same time, so the inter-pass twiddle and prescale records
 // of that position, and in coset mode the input tile shared by a column's cosets, come from L2
 // instead of once per slot from memory.
-template <bool BIG>
+template <bool BIG, int LR = 0>
 __global__ __launch_bounds__(NTT_THREADS, 4) void ntt_pass_kernel(const NttPassArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const Tile tile(lds_raw);
@@ -344,7 +361,7 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void ntt_pass_kernel(const NttPassA
   const int poly = (a.first && a.cosets) ? slot / a.cosets : slot;
   const uint64_t* __restrict__ in = a.batch.src(poly);
   uint64_t* __restrict__ out = a.batch.dst(slot);
-  const int log_c = a.log_c, log_r = a.log_r, log_inner = a.log_inner;
+  const int log_c = LR ? NTT_TILE_LOG - LR : a.log_c, log_r = LR ? LR : a.log_r, log_inner = a.log_inner;
   const int tiles_per_block = 1 << (log_inner - log_c);       // tiles per value of the outer digits
   const uint64_t o = tile_id >> (log_inner - log_c);
   const uint64_t q0 = (uint64_t)(tile_id & (tiles_per_block - 1)) << log_c;
@@ -375,7 +392,7 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void ntt_pass_kernel(const NttPassA
                            : twiddle_two_level(hi, a.tab.tw_lo, a.tab.lo_bits, ((uint64_t)k * q) << shift);
         fe_store(out, base + ((uint64_t)k << log_inner) + c, fe_pack_f9(mont29(v, tw)));
       };
-  tile_transform_any<BIG>(tile, log_r, log_c, a.tab.master, a.tab.master_sh, quarter, load, store);
+  tile_transform_any<BIG, LR>(tile, log_r, log_c, a.tab.master, a.tab.master_sh, quarter, load, store);
 }
 
 struct NttFinalArgs {
@@ -399,7 +416,7 @@ struct NttFinalArgs {
 // Row o_c = (k1_0 + c) * R2 + k2 of the pass-major buffer feeds column c of the tile; a thread of the
 // first step reads its four elements of that row straight from memory (32-byte pieces; the row's
 // lines are shared by neighbouring waves of the workgroup through the vector cache).
-template <bool BIG>
+template <bool BIG, int LR = 0>
 __global__ __launch_bounds__(NTT_THREADS, 4) void ntt_final_kernel(const NttFinalArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const Tile tile(lds_raw);
@@ -408,7 +425,7 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void ntt_final_kernel(const NttFina
   const int poly = a.first ? col : slot;
   const uint64_t* __restrict__ in = a.batch.src(poly);
   uint64_t* __restrict__ out = a.batch.dst(col) + (a.cosets ? (uint64_t)(slot % a.cosets) * a.coset_stride : 0);
-  const int log_c = a.log_c, log_r = a.log_r;
+  const int log_c = LR ? NTT_TILE_LOG - LR : a.log_c, log_r = LR ? LR : a.log_r;
   const uint64_t k2 = blockIdx.x & ((1u << a.log_r2) - 1);
   const uint64_t k1_0 = (uint64_t)(blockIdx.x >> a.log_r2) << log_c;
   const uint32_t kind = a.first ? a.batch.kind_of(poly) : (uint32_t)NTT_IN_FIELD;
@@ -431,7 +448,7 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void ntt_final_kernel(const NttFina
         const uint64_t dst = (k1_0 + c) + (k2 << a.log_r1) + ((uint64_t)k << (a.log_r1 + a.log_r2));
         fe_store(out, dst, fe_reduce_f9(scaled ? mont29(v, f9_load_tw(a.tab.scale, 0)) : v));
       };
-  tile_transform_any<BIG>(tile, log_r, log_c, a.tab.master, a.tab.master_sh, quarter, load, store);
+  tile_transform_any<BIG, LR>(tile, log_r, log_c, a.tab.master, a.tab.master_sh, quarter, load, store);
 }
 
 // ---- the local phases of a four-step transform sharded over G ranks ---------------------------------------------
