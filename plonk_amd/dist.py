@@ -62,8 +62,9 @@ def _all_to_all(send: torch.Tensor, group=None) -> torch.Tensor:
         recv = torch.empty_like(host)
         dist.all_to_all_single(recv, host, group=group)
         return recv.to(send.device)
+    send = send.contiguous()                 # (the collective takes contiguous buffers on both sides)
     recv = torch.empty_like(send)
-    dist.all_to_all_single(recv, send.contiguous(), group=group)
+    dist.all_to_all_single(recv, send, group=group)
     return recv
 
 
