@@ -19,7 +19,7 @@ from plonk_amd.device import DeviceProver, to_device, to_host
 
 
 def main():
-    faulthandler.dump_traceback_later(150, exit=True)
+    faulthandler.dump_traceback_later(240, exit=True)
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     eng = DeviceProver(0)
@@ -49,6 +49,23 @@ def main():
     assert torch.equal(blk, direct.view(N2, N1, 4)[:, rank * r1:(rank + 1) * r1].permute(1, 0, 2)), "four-step at 2^20, transposed output"
     assert torch.equal(pdist.four_step_ntt(got, N, eng, inverse=True), shard), "four-step at 2^20, inverse"
     del direct, blk, got
+
+    if world == 2:
+        # the full size of the sharded-transform configuration, 2^24 points: every rank builds the same input on the
+        # device, transforms its shard through the exchanges and compares with its range of the direct transform
+        N = 1 << 24
+        g = torch.Generator(device=d)
+        g.manual_seed(2024)
+        x = torch.randint(-(1 << 63), (1 << 63) - 1, (N, 4), dtype=torch.int64, device=d, generator=g)
+        x[:, 3] &= (1 << 62) - 1                                             # below 2^254: reduced elements
+        lo, hi = rank * N // world, (rank + 1) * N // world
+        direct = eng.ntt_batch([x], N)[0][lo:hi].clone()
+        shard = x[lo:hi].clone()
+        del x
+        got = pdist.four_step_ntt(shard, N, eng)
+        assert torch.equal(got, direct), "four-step at 2^24, natural order"
+        assert torch.equal(pdist.four_step_ntt(got, N, eng, inverse=True), shard), "four-step at 2^24, inverse"
+        del direct, got, shard
 
     for rows_n in (1 << 12, 3001):               # even and uneven row blocks
         cc = synth.make_circuit(1 << 12, circuit_id=5)

@@ -68,7 +68,8 @@ def test_poly_sharded_round23_single_rank(prover):
 @pytest.mark.parametrize("world", [2, 4])
 def test_ranks_share_the_gpu(world):
     """several ranks on GPU 0 (exchanges over gloo): the sharded transform and the one-proof-over-G-ranks
-    path with the HIP engine, against the CPU oracle."""
+    path with the HIP engine, against the CPU oracle; with two ranks also the sharded transform at its full
+    configured size, 2^24 points, against the direct transform."""
     import os
     import subprocess
     import sys
