@@ -40,6 +40,9 @@ struct GpScratch {
 };
 
 
+#ifndef PLK_GP_FUSED_APPLY
+#define PLK_GP_FUSED_APPLY 1
+#endif
 #ifndef PLK_FIXED_RADIX
 #define PLK_FIXED_RADIX 1
 #endif
@@ -843,6 +846,10 @@ int launch_grand_product(plk_ctx* ctx, hipStream_t s, const uint64_t* const wire
     static_assert(GP_SMALL_ROWS / GP_THREADS <= GP_THREADS, "gp_apply_small_kernel: one thread per earlier block");
     ProfScope ps(ctx, s, "gp_apply_small_kernel", 0.0, (double)n);
     hipLaunchKernelGGL(gp_apply_small_kernel, dim3((unsigned)(nb - 1)), dim3(GP_THREADS), 0, s, z_out + 4, (uint64_t)n, (const uint64_t*)ratio);
+    HIP_TRY(ctx, hipGetLastError());
+  } else if (nb > 1 && nb <= (size_t)GP_BLOCK_ROWS && PLK_GP_FUSED_APPLY) {
+    ProfScope ps(ctx, s, "gp_apply_fused_kernel", 0.0, (double)n);
+    hipLaunchKernelGGL(gp_apply_fused_kernel<GP_ITEMS>, dim3((unsigned)(nb - 1)), dim3(GP_THREADS), 0, s, z_out + 4, (uint64_t)n, (const uint64_t*)ratio);
     HIP_TRY(ctx, hipGetLastError());
   } else if (nb > 1) {
     {
@@ -1812,10 +1819,14 @@ int plk_ctx_create(int device, plk_ctx** out) {
     CTX_TRY(hipFuncGetAttributes(&fa, (const void*)gp_ratio_scan_kernel));
     CTX_TRY(hipFuncGetAttributes(&fa, (const void*)gp_apply_kernel<GP_ITEMS>));
     CTX_TRY(hipFuncGetAttributes(&fa, (const void*)gp_apply_small_kernel));
+    CTX_TRY(hipFuncGetAttributes(&fa, (const void*)gp_apply_fused_kernel<GP_ITEMS>));
     CTX_TRY(hipFuncGetAttributes(&fa, (const void*)gp_local_z_small_kernel));
   }
   CTX_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES));
   CTX_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES));
+  CTX_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel<true, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES));
+  CTX_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel<true, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES));
+  CTX_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES));
   CTX_TRY(hipFuncSetAttribute((const void*)ntt_final_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES));
   CTX_TRY(hipFuncSetAttribute((const void*)ntt_final_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES));
   CTX_TRY(hipFuncSetAttribute((const void*)ntt_fs_kernel<FS_A_FIRST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES));

@@ -299,6 +299,29 @@ __global__ __launch_bounds__(GP_THREADS) void gp_apply_small_kernel(uint64_t* z_
   if (j < n) fe_store(z_after, j, fe_mul(fe_load(z_after, j), c));
 }
 
+// The same for blocks of GP_THREADS * ITEMS rows, at most that many of them (2^20 rows at four items): a thread
+// multiplies ITEMS of the earlier blocks' ratios, the workgroup the 256 partial products; about a dozen dependent
+// products per workgroup, all workgroups at once, where the one-workgroup scan kernel took longer than the apply itself.
+template <int ITEMS>
+__global__ __launch_bounds__(GP_THREADS) void gp_apply_fused_kernel(uint64_t* z_after, uint64_t n, const uint64_t* ratio) {
+  __shared__ Fe lds[GP_THREADS / 64];
+  const uint32_t b = blockIdx.x + 1;
+  Fe prod = fe_one();
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const uint32_t i = (uint32_t)k * GP_THREADS + threadIdx.x;            // consecutive threads, consecutive ratios
+    if (i < b) prod = (k == 0) ? fe_load(ratio, i) : fe_mul(prod, fe_load(ratio, i));
+  }
+  Fe c;
+  block_scan_mul<GP_THREADS, false>(prod, lds, &c);
+  const uint64_t base = (uint64_t)b * GP_THREADS * ITEMS;
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const uint64_t j = base + (uint64_t)it * GP_THREADS + threadIdx.x;
+    if (j < n) fe_store(z_after, j, fe_mul(fe_load(z_after, j), c));
+  }
+}
+
 // ---- row-range form (rows split over several GPUs): terms, block products, carries, finish ---------------------
 
 // Kernel 1: per-row numerator / denominator terms and per-block products, for the rows

@@ -25,6 +25,7 @@ BY_GRID = {
     "gp_local_z_kernel": [["gp_local_z_kernel"]],
     "gp_ratio_scan_kernel": [["gp_ratio_scan_kernel"]],
     "gp_apply_kernel": [["gp_apply_kernel"]],
+    "gp_apply_fused_kernel": [["gp_apply_fused_kernel"]],
     # (a 2^20-point transform takes two passes: one ntt_pass launch and the final one; with three passes each
     # list here held p0 and p1)
     "ntt_pass_kernel": [["ntt_pass_kernel/intt20/side/p0"],
