@@ -11,7 +11,7 @@ from plonk_amd import dist as pdist
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world,port", [(2, 29731), (4, 29732)])
+@pytest.mark.parametrize("world,port", [(2, 29731), (4, 29732), (8, 29733)])
 def test_dist_paths_over_gloo(world, port):
     env = dict(os.environ, OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
