@@ -65,7 +65,7 @@ def test_poly_sharded_round23_single_rank(prover):
     assert np.array_equal(to_host(z), zr) and np.array_equal(to_host(g), gr) and np.array_equal(to_host(e), er)
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_ranks_share_the_gpu(world):
     """several ranks on GPU 0 (exchanges over gloo): the sharded transform and the one-proof-over-G-ranks
     path with the HIP engine, against the CPU oracle; with two ranks also the sharded transform at its full
