@@ -41,7 +41,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--log-n", type=int, default=20, help="log2 of the number of rows")
+    ap.add_argument("--log-n", type=int, default=None,
+                    help="log2 of the number of rows (default: 20; 24 for --workload ntt and 18 for --workload batch, the sizes "
+                         "of the sharded-transform and batched-proof configurations)")
     ap.add_argument("--blowup", type=int, default=4, help="evaluation domain = blowup * n")
     ap.add_argument("--workload", default="round23", choices=["round23", "ntt", "round23-sharded", "batch", "tables", "quotient", "msm"],
                     help="round23: the headline metric (default). ntt: ONE four-step transform of 2^log-n points sharded over "
@@ -56,7 +58,10 @@ def parse_args():
     ap.add_argument("--no-profile", action="store_true", help="time the steps without the per-launch events (no roofline object)")
     ap.add_argument("--no-lean-variant", action="store_true",
                     help="skip the extra figure without the Int/Bool selector columns (a profiler run wants one launch shape per kernel)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.log_n is None:
+        args.log_n = {"ntt": 24, "batch": 18}.get(args.workload, 20)
+    return args
 
 
 def cpu_baseline(log_n_full: int, blowup: int, sample_log_n: int):
