@@ -8,9 +8,13 @@ permutation-constraint evaluation.  Inputs are resident in HBM before the timed 
 
     python bench.py --gpus N --steps K --warmup W
 
-With N > 1 (one process per GPU, launched through torch.distributed.run) every rank proves its
-own circuit per step (batched-proof mode, no data-path collective): weak scaling.  `value` is
-the time per circuit over the whole job, ms_per_step / N.
+With N > 1 every rank (one process per GPU) proves its own circuit per step (batched-proof mode, no
+data-path collective): weak scaling.  `value` is the time per circuit over the whole job,
+ms_per_step / N.  The ranks come either from an outer `python -m torch.distributed.run ... bench.py
+--gpus N` (WORLD_SIZE is then set) or, when bench.py is started alone with --gpus N > 1, from this
+script itself: before anything touches the GPU it starts that same launcher as a child process,
+relays the child's output and leaves with its exit code.  A run whose world size differs from
+--gpus ends with a non-zero status instead of a line that claims another N.
 
 Prints ONE JSON line (rank 0).
 """
@@ -65,8 +69,10 @@ def parse_args():
 
 
 def cpu_baseline(log_n_full: int, blowup: int, sample_log_n: int):
-    """The C restatement of the reference algorithm (oracle/plonk_oracle.c) timed on this host
-    on a smaller circuit of the same shape, scaled linearly in the number of rows."""
+    """The C restatement of the reference algorithm (oracle/plonk_oracle.c) timed on this host on circuit 0 of
+    2^sample_log_n rows (the whole workload when that is log_n_full, else scaled linearly in the number of rows).
+    Returns (the bench line's object, the circuit, the oracle's (z, gate, perm)): the caller checks the GPU's
+    outputs for that circuit against them."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import c_oracle as co
     from plonk_amd import synth
@@ -75,7 +81,7 @@ def cpu_baseline(log_n_full: int, blowup: int, sample_log_n: int):
     threads = min(co.num_threads(), 16)
     co.set_num_threads(threads)
     t0 = time.perf_counter()
-    co.round23(c.table.wires(), c.table.selectors, c.perm.columns(), blowup * ns, c.beta, c.gamma)
+    ref = co.round23(c.table.wires(), c.table.selectors, c.perm.columns(), blowup * ns, c.beta, c.gamma)
     dt = time.perf_counter() - t0
     scale = float(1 << (log_n_full - sample_log_n))
     scaled = f"; scaled x{int(scale)} by row count (ignores the log factor of the transforms)" if scale != 1 else "; the full workload, unscaled"
@@ -84,7 +90,7 @@ def cpu_baseline(log_n_full: int, blowup: int, sample_log_n: int):
         "sample": f"one round 2+3 at n=2^{sample_log_n}, N=2^{sample_log_n + blowup.bit_length() - 1} took {dt:.2f} s "
                   f"(transforms on {threads} OpenMP threads, grand-product and constraint loops single-threaded as in the "
                   f"reference)" + scaled,
-    }
+    }, c, ref
 
 
 def pmc_record(label: str):
@@ -356,8 +362,25 @@ def four_step_extra(prover, dist, world, device, log_N=24, steps=5, warmup=2):
             "transposed_output_ms": round(ms_t, 4), "round_trip_bit_exact": bool(int(ok.item())), "steps": steps, "scaling": "strong"}
 
 
+def launch_ranks(args) -> int:
+    """bench.py started alone with --gpus N > 1: start N ranks of this same command line through
+    torch.distributed.run as a CHILD process (this process has not touched the GPU and never will), pass the child's
+    stdout and stderr through, and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:               # a port nobody listens on right now
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     import torch
     from plonk_amd import synth
     from plonk_amd.device import DeviceProver
@@ -368,6 +391,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        # the line would claim a number of GPUs that did not run
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)", file=sys.stderr, flush=True)
+        sys.exit(2)
     dist = None
     # Rehearsal on a box with fewer GPUs than ranks: PLONK_BENCH_SHARE_GPU=1 maps ranks onto the GPUs
     # present and PLONK_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device).
@@ -503,7 +530,24 @@ def main():
                          "Gproducts_per_s": round(r.get("products", 0.0) / max(r["total_ms"], 1e-9) / 1e6, 1)} for r in prof],
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.log_n, args.blowup, min(args.cpu_sample_log_n, args.log_n))
+            # the CPU restatement on circuit 0, timed; and the GPU's three vectors for that same circuit compared with
+            # its results IN FULL (the timed run's own outputs when the sample is the whole workload)
+            from plonk_amd.device import to_host
+            sample_log_n = min(args.cpu_sample_log_n, args.log_n)
+            line["cpu_baseline"], c_ref, ref = cpu_baseline(args.log_n, args.blowup, sample_log_n)
+            if sample_log_n == args.log_n:
+                got = out
+            else:
+                got = prover.round23(prover.upload(c_ref), args.blowup << sample_log_n)
+                prover.status()
+            import numpy as np
+            same = [bool(np.array_equal(to_host(g), r)) for g, r in zip(got, ref)]
+            line["matches_cpu"] = all(same)
+            line["matches_cpu_detail"] = {"z": same[0], "gate_constraints": same[1], "permutation_constraints": same[2],
+                                          "rows": 1 << sample_log_n, "points": args.blowup << sample_log_n,
+                                          "what": "every element of the three output vectors of "
+                                                  + ("the timed run" if sample_log_n == args.log_n else "a run on the sample circuit")
+                                                  + " against the C restatement of the reference"}
     else:
         line = None
 
@@ -516,24 +560,39 @@ def main():
 
         def watchdog():
             if not done.wait(args.four_step_limit):
+                # a stuck exchange: the headline line still goes out, and every rank leaves with a status that says so
+                print(f"bench.py: rank {rank} of {world}: the sharded 2^24-point transform (three all-to-all exchanges) did not "
+                      f"finish within {args.four_step_limit} s; pending since the timed region ended", file=sys.stderr, flush=True)
                 if rank == 0:
                     line["four_step"] = {"error": f"did not finish within {args.four_step_limit} s"}
                     print(json.dumps(line), flush=True)
-                os._exit(0)
+                os._exit(3)
 
         threading.Thread(target=watchdog, daemon=True).start()
         try:
             extra = four_step_extra(prover, dist, world, prover.device)
-        except Exception as e:   # noqa: BLE001 - whatever the exchange raised, the main figure still goes out
+        except Exception as e:   # noqa: BLE001 - whatever the exchange raised, the main figure still goes out ...
             extra = {"error": f"{type(e).__name__}: {e}"[:300]}
+            print(f"bench.py: rank {rank} of {world}: the sharded transform failed: {extra['error']}", file=sys.stderr, flush=True)
+            if rank == 0:
+                line["four_step"] = extra
+                print(json.dumps(line), flush=True)
+            os._exit(5)          # ... and the status says that the run was not clean (the other ranks leave by their watchdogs)
         done.set()
         if rank == 0:
             line["four_step"] = extra
+            if extra.get("round_trip_bit_exact") is False:
+                print(json.dumps(line), flush=True)
+                print("bench.py: the sharded transform's forward-then-inverse round trip did not return its input", file=sys.stderr, flush=True)
+                os._exit(6)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if line is not None and line.get("matches_cpu") is False:
+        print("bench.py: the GPU's outputs differ from the CPU restatement: " + json.dumps(line["matches_cpu_detail"]), file=sys.stderr, flush=True)
+        sys.exit(4)
 
 
 if __name__ == "__main__":

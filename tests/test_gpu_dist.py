@@ -127,3 +127,24 @@ def test_grand_product_by_row_ranges(prover, n, ranges):
         z_blk = prover.grand_product_finish(r, totals, g)
         prover.status()
         assert np.array_equal(to_host(z_blk), want[f + 1:f + 1 + r]), (g, f, r)
+
+
+def test_bench_starts_its_own_ranks():
+    """`bench.py --gpus 2` started alone (no launcher around it) starts two ranks itself as a child process and prints
+    ONE line that says so, with the sharded transform's figure in it; here the two ranks share GPU 0 and exchange
+    over gloo, because RCCL wants one GPU per rank."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(PLONK_BENCH_SHARE_GPU="1", PLONK_BENCH_BACKEND="gloo", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--log-n", "16"],
+                       env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["config"]["circuits_per_step"] == 2
+    assert line["four_step"]["round_trip_bit_exact"] is True and line["four_step"]["ms"] > 0

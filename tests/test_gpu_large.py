@@ -48,15 +48,22 @@ def test_grand_product_2_20_vs_serial_recurrence(prover, big):
 
 
 def test_round23_2_20(prover, big):
-    """The n = 2^20, N = 2^22 configuration.  Checks: Z against the serial recurrence; the two constraint vectors at random
-    points recomputed in big integers from the evaluated columns' definition (Horner on the coefficient
-    vectors); the restriction of the gate-constraint vector to the trace domain against the direct
+    """The n = 2^20, N = 2^22 configuration.  Checks: all three outputs IN FULL against the C restatement of the
+    reference (Z: the serial recurrence of src/permutation_polynomial.rs:217-261; the gate and permutation vectors:
+    the loops of src/execution_trace.rs:357-431 and src/permutation_polynomial.rs:312-376 over all 2^22 points); the
+    two constraint vectors at random points recomputed in big integers from the evaluated columns' definition (Horner
+    on the coefficient vectors); the restriction of the gate-constraint vector to the trace domain against the direct
     row-wise formula."""
     c, dc = big
     z, g, e = prover.round23(dc, N_EVAL)
     prover.status()
     z_h = to_host(z)
-    assert np.array_equal(z_h, co.grand_product(c.table.wires(), c.perm.columns(), c.beta, c.gamma))
+    co.set_num_threads(min(co.num_threads(), 16))
+    z_ref, g_ref, e_ref = co.round23(c.table.wires(), c.table.selectors, c.perm.columns(), N_EVAL, c.beta, c.gamma)
+    assert np.array_equal(z_h, z_ref)
+    assert np.array_equal(to_host(g), g_ref)
+    assert np.array_equal(to_host(e), e_ref)
+    del z_ref, g_ref, e_ref
 
     # coefficient vectors through the library's own iNTT (parity of the iNTT itself is covered above and in test_gpu_parity)
     cols = dc.wires + [dc.selectors[k] for k in po.AST_KINDS] + [z[:N_ROWS].contiguous()]
