@@ -20,10 +20,20 @@
  *    enqueue on the given hipStream_t (passed as void*); data-dependent failures (zero
  *    denominator, sigma out of range) are reported by plk_dev_status().
  *  - One context per GPU; a context must not be used from two threads at once.  The context's workspace, status
- *    word and side stream are shared by all its calls, so the library orders them: a device call given another
- *    stream than the context's previous call first makes that stream wait (hipStreamWaitEvent) for the work the
- *    previous call enqueued.  Calls on one context therefore never overlap on the GPU; use one context per
- *    stream for overlap (except plk_dev_grand_product_noalloc, whose fixed array is shared per GPU).
+ *    word and side stream are shared by all its calls, so the library orders them: every device call ends by
+ *    recording an event on the stream it was given, and a call given another stream than the context's previous
+ *    call first makes that stream wait (hipStreamWaitEvent) for that event.  Calls on one context therefore never
+ *    overlap on the GPU; use one context per stream for overlap (except plk_dev_grand_product_noalloc, whose fixed
+ *    array is shared per GPU).
+ *  - Stream lifetime: a stream handle is used only inside the call that brings it; the library keeps no handle
+ *    of the caller's.  A stream may be destroyed as soon as the work enqueued on it has finished (per-request
+ *    streams are fine); destroying it with library work still pending is the caller's race, as with any HIP work.
+ *  - HIP graph capture: a call on a stream that is being captured takes no part in the ordering above (an event
+ *    recorded into a capture cannot be waited for from outside it): its launches are ordered by the graph, and the
+ *    caller orders the graph's replays against other calls on the context.  Only entry points that neither
+ *    allocate nor synchronise are valid under capture: plk_dev_grand_product_noalloc, and the other plk_dev_*
+ *    calls once their workspace and tables exist from an earlier identical call (not plk_dev_status, not the msm
+ *    calls, which wait for the stream).
  *  - Preconditions on data, not checked: every element of every column is reduced (< p), as ark-ff guarantees
  *    for `Fp256`; an unreduced limb pattern gives a wrong element, not an error.  beta, gamma, shift, alpha and
  *    default_val ARE checked (PLK_ERR_ARG).

@@ -80,6 +80,8 @@ constexpr size_t NOALLOC_MAX_ROWS = size_t(1) << 20;
 constexpr size_t NOALLOC_MAX_BLOCKS = (NOALLOC_MAX_ROWS + GP_BLOCK_ROWS - 1) / GP_BLOCK_ROWS;
 constexpr size_t NOALLOC_SCRATCH_BYTES = NOALLOC_MAX_BLOCKS * ELEM;   // one block ratio per GP_BLOCK_ROWS rows: 32 KiB
 static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
+static_assert(NOALLOC_MAX_ROWS == PLK_NOALLOC_MAX_ROWS, "the header's limit and the array's size are one number");
+static_assert(GP_SMALL_ROWS / GP_THREADS <= NOALLOC_MAX_BLOCKS, "the small-circuit path (one row per thread) keeps its block ratios in the same array");
 
 // Copies between ordinary (pageable) host memory and the device.  hipMemcpy stages such copies through one
 // thread; here COPY_WORKERS threads (the caller and a small pool that lives with the context) each copy chunks
@@ -146,14 +148,12 @@ struct plk_ctx {
   hipStream_t stream = nullptr;  // used by the host entry points
   hipStream_t aux = nullptr;     // side stream of plk_round23: the grand-product chain runs beside the transforms
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  // The workspace, the status word and the side stream are shared by every call on the context, so calls are
-  // ordered one after another whatever stream they are given: when a device call arrives on another stream
-  // than the previous one, the new stream first waits for an event recorded at the end of the old one.
+  // (calls on different streams are ordered one after another through ev_order: StreamCall below)
   // plk_round23 on host arrays: uploads, kernels and downloads overlap on streams of their own
   hipStream_t copy_up = nullptr, copy_down = nullptr;
   hipEvent_t ev_pipe[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  hipStream_t last_stream = nullptr;
-  bool have_last_stream = false;
+  hipStream_t order_stream = nullptr;   // the stream ev_order was last recorded on (a value to compare with, nothing more)
+  bool have_order = false;
   hipEvent_t ev_order = nullptr;
   std::map<std::pair<int, int>, NttPlan> plans;  // (log_n, inverse)
   DevBuf master_sh[2];                           // in-tile twiddle pairs for the precomputed-quotient product, per direction
@@ -790,10 +790,9 @@ int gp_finish(plk_ctx* ctx, hipStream_t s, uint64_t* z_after, uint64_t* z0) {
 int launch_grand_product(plk_ctx* ctx, hipStream_t s, const uint64_t* const wires[4], const uint64_t* const sigma[4],
                          size_t n, const uint64_t beta_[4], const uint64_t gamma_[4], uint64_t* z_out, uint64_t* fixed = nullptr) {
   if (!z_out || !beta_ || !gamma_) return fail(ctx, PLK_ERR_ARG, "null pointer");
-  if (n == 0) {  // z = [1]
-    const Fe one = fe_one();
-    HIP_TRY(ctx, hipMemcpyAsync(z_out, &one, ELEM, hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));
+  if (n == 0) {  // z = [1], written by a kernel: no host memory is read and nothing waited for (valid under graph capture too)
+    hipLaunchKernelGGL(fe_fill_kernel, dim3(1), dim3(64), 0, s, z_out, (uint64_t)1, fe_one());
+    HIP_TRY(ctx, hipGetLastError());
     return PLK_OK;
   }
   const Fe beta = fe_from_limbs64(beta_), gamma = fe_from_limbs64(gamma_);
@@ -1647,7 +1646,7 @@ int round23_host_pipelined(plk_ctx* ctx, const uint64_t* const wires[4], const u
   if (perm_out && (rc = st.alloc(N * ELEM, &dp))) return rc;
   R23Ws ws;
   if ((rc = r23_workspace(ctx, n, N, (uint64_t*)dz, &ws))) return rc;
-  // the copy streams start behind whatever the context's stream has been given so far (use_host_stream has ordered
+  // the copy streams start behind whatever the context's stream has been given so far (the call guard has ordered
   // that behind the context's earlier calls): the staging buffers may still be read by them
   HIP_TRY(ctx, hipEventRecord(ctx->ev_pipe[EV_PERM], s));
   HIP_TRY(ctx, hipStreamWaitEvent(up, ctx->ev_pipe[EV_PERM], 0));
@@ -1748,25 +1747,54 @@ int round23_host_pipelined(plk_ctx* ctx, const uint64_t* const wires[4], const u
   return rc;
 }
 
-// Prologue of every entry point that enqueues on a stream: use_device, then order the stream behind the
-// context's previous call if that went to another stream.
-int use_stream(plk_ctx* ctx, hipStream_t s) {
-  int rc = use_device(ctx);
-  if (rc) return rc;
-  if (ctx->have_last_stream && ctx->last_stream != s) {
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_order, ctx->last_stream));
-    HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_order, 0));
+// Every entry point that enqueues on a stream holds one of these for the length of the call.  The workspace, the
+// status word and the side stream are shared by every call on the context, so calls are ordered one after another
+// whatever stream they are given: the call's last act (destructor) records ev_order on ITS OWN stream - a handle
+// that is certainly alive, the caller being inside the call - and the next call, if it comes on another stream,
+// makes that stream wait for the event.  The library never touches a caller's stream handle after the call that
+// brought it has returned, so a caller may destroy a stream once the work it gave it has finished.
+// A stream under HIP graph capture is left out of this protocol (an event recorded into a capture cannot be waited
+// for from outside it, and the wait would pull the other stream into the capture): the captured launches are
+// ordered by the graph, and the caller orders the graph's replays against other calls on the context.
+struct StreamCall {
+  plk_ctx* ctx;
+  hipStream_t s;
+  bool capturing = false;
+  int rc;
+  StreamCall(plk_ctx* c, hipStream_t st) : ctx(c), s(st) { rc = begin(); }
+  StreamCall(const StreamCall&) = delete;
+  StreamCall& operator=(const StreamCall&) = delete;
+  int begin() {
+    int r = use_device(ctx);
+    if (r) return r;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+    if (cs == hipStreamCaptureStatusActive) { capturing = true; return PLK_OK; }
+    if (ctx->have_order && ctx->order_stream != s) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_order, 0));
+    return PLK_OK;
   }
-  ctx->last_stream = s;
-  ctx->have_last_stream = true;
-  return PLK_OK;
-}
+  ~StreamCall() {
+    if (rc != PLK_OK || capturing) return;
+    if (hipEventRecord(ctx->ev_order, s) == hipSuccess) {
+      ctx->have_order = true;
+      ctx->order_stream = s;           // compared by value only, never used as a stream again
+    } else {                           // cannot leave a marker: wait here, so that the next call has nothing to wait for
+      (void)hipGetLastError();
+      (void)hipDeviceSynchronize();
+      ctx->have_order = false;
+    }
+  }
+};
 
-// the host entry points enqueue on the context's own stream
-int use_host_stream(plk_ctx* ctx) {
-  if (!ctx) return PLK_ERR_ARG;
-  return use_stream(ctx, ctx->stream);
-}
+// `STREAM_CALL(ctx, stream)` opens an entry point that enqueues on the caller's stream, `HOST_CALL(ctx)` one that
+// enqueues on the context's own.
+#define STREAM_CALL(ctx, stream)                     \
+  StreamCall call_(ctx, (hipStream_t)(stream));      \
+  if (call_.rc) return call_.rc
+#define HOST_CALL(ctx)                               \
+  if (!(ctx)) return PLK_ERR_ARG;                    \
+  StreamCall call_(ctx, (ctx)->stream);              \
+  if (call_.rc) return call_.rc
 
 }  // namespace
 
@@ -1956,8 +1984,8 @@ const char* plk_profile_end(plk_ctx* ctx) {
 
 int plk_dev_ntt_batch(plk_ctx* ctx, void* stream, const uint64_t* const* in, const uint32_t* kinds, size_t batch,
                       size_t n_in, size_t N, int inverse, uint64_t* const* out) {
-  int rc = use_stream(ctx, (hipStream_t)stream);
-  if (rc) return rc;
+  STREAM_CALL(ctx, stream);
+  int rc;
   if (!in || !out) return fail(ctx, PLK_ERR_ARG, "null pointer table");
   for (size_t done = 0; done < batch; done += NTT_MAX_BATCH) {
     const size_t m = std::min<size_t>(NTT_MAX_BATCH, batch - done);
@@ -1969,16 +1997,14 @@ int plk_dev_ntt_batch(plk_ctx* ctx, void* stream, const uint64_t* const* in, con
 
 int plk_dev_grand_product(plk_ctx* ctx, void* stream, const uint64_t* const wires[4], const uint64_t* const sigma[4], size_t n,
                           const uint64_t beta[4], const uint64_t gamma[4], uint64_t* z_out) {
-  int rc = use_stream(ctx, (hipStream_t)stream);
-  if (rc) return rc;
+  STREAM_CALL(ctx, stream);
   if (!wires || !sigma) return fail(ctx, PLK_ERR_ARG, "null pointer table");
   return launch_grand_product(ctx, (hipStream_t)stream, wires, sigma, n, beta, gamma, z_out);
 }
 
 int plk_dev_grand_product_noalloc(plk_ctx* ctx, void* stream, const uint64_t* const wires[4], const uint64_t* const sigma[4], size_t n,
                                   const uint64_t beta[4], const uint64_t gamma[4], uint64_t* z_out) {
-  int rc = use_stream(ctx, (hipStream_t)stream);
-  if (rc) return rc;
+  STREAM_CALL(ctx, stream);
   if (!wires || !sigma) return fail(ctx, PLK_ERR_ARG, "null pointer table");
   if (n > NOALLOC_MAX_ROWS)
     return fail(ctx, PLK_ERR_ARG, "plk_dev_grand_product_noalloc takes at most " + std::to_string(NOALLOC_MAX_ROWS) + " rows, got " +
@@ -1991,46 +2017,41 @@ int plk_dev_grand_product_noalloc(plk_ctx* ctx, void* stream, const uint64_t* co
 
 int plk_dev_grand_product_local(plk_ctx* ctx, void* stream, const uint64_t* const wires[4], const uint64_t* const sigma[4], size_t n,
                                 size_t first, size_t rows, const uint64_t beta[4], const uint64_t gamma[4], uint64_t* totals_out) {
-  int rc = use_stream(ctx, (hipStream_t)stream);
-  if (rc) return rc;
+  STREAM_CALL(ctx, stream);
   if (!wires || !sigma || !totals_out) return fail(ctx, PLK_ERR_ARG, "null pointer");
   return gp_local(ctx, (hipStream_t)stream, wires, sigma, n, first, rows, beta, gamma, totals_out);
 }
 
 int plk_dev_grand_product_finish(plk_ctx* ctx, void* stream, size_t rows, const uint64_t* totals_all, size_t ranges, size_t mine,
                                  uint64_t* z_after_out) {
-  int rc = use_stream(ctx, (hipStream_t)stream);
-  if (rc) return rc;
+  STREAM_CALL(ctx, stream);
+  int rc;
   if (rows == 0 || rows != ctx->gp_rows) return fail(ctx, PLK_ERR_ARG, "rows differ from the preceding plk_dev_grand_product_local");
   if ((rc = gp_apply_carries(ctx, (hipStream_t)stream, totals_all, ranges, mine))) return rc;
   return gp_finish(ctx, (hipStream_t)stream, z_after_out, nullptr);
 }
 
 int plk_dev_msm_set_bases(plk_ctx* ctx, const uint64_t* bases_dev, size_t n) {
-  int rc = use_host_stream(ctx);
-  if (rc) return rc;
+  HOST_CALL(ctx);
   if (!bases_dev && n) return fail(ctx, PLK_ERR_ARG, "null pointer");
   HIP_TRY(ctx, hipDeviceSynchronize());          // the caller's table may have been written on any stream
   return msm_build_table(ctx, ctx->stream, bases_dev, n);
 }
 
 int plk_dev_msm_g1(plk_ctx* ctx, void* stream, const uint64_t* scalars_dev, size_t n, uint64_t out_xy[12]) {
-  int rc = use_stream(ctx, (hipStream_t)stream);
-  if (rc) return rc;
+  STREAM_CALL(ctx, stream);
   if (!scalars_dev && n) return fail(ctx, PLK_ERR_ARG, "null pointer");
   const uint64_t* one[1] = {scalars_dev};
   return launch_msm(ctx, (hipStream_t)stream, one, 1, n, out_xy);
 }
 
 int plk_dev_msm_g1_batch(plk_ctx* ctx, void* stream, const uint64_t* const scalars_dev[], size_t count, size_t n, uint64_t* out_xy) {
-  int rc = use_stream(ctx, (hipStream_t)stream);
-  if (rc) return rc;
+  STREAM_CALL(ctx, stream);
   return launch_msm(ctx, (hipStream_t)stream, scalars_dev, count, n, out_xy);
 }
 
 int plk_dev_g1_multiples(plk_ctx* ctx, void* stream, const uint64_t base_xy[12], uint64_t first, size_t count, uint64_t* out_dev) {
-  int rc = use_stream(ctx, (hipStream_t)stream);
-  if (rc) return rc;
+  STREAM_CALL(ctx, stream);
   if (!base_xy || (!out_dev && count)) return fail(ctx, PLK_ERR_ARG, "null pointer");
   if (count == 0) return PLK_OK;
   G1Affine b;
@@ -2045,8 +2066,8 @@ int plk_dev_g1_multiples(plk_ctx* ctx, void* stream, const uint64_t base_xy[12],
 
 int plk_dev_coset_ntt(plk_ctx* ctx, void* stream, const uint64_t* const* in, size_t batch, size_t n_in, size_t N, const uint64_t shift[4],
                       int inverse, uint64_t* const* out) {
-  int rc = use_stream(ctx, (hipStream_t)stream);
-  if (rc) return rc;
+  STREAM_CALL(ctx, stream);
+  int rc;
   if (!in || !out) return fail(ctx, PLK_ERR_ARG, "null pointer table");
   for (size_t done = 0; done < batch; done += NTT_MAX_BATCH) {
     const size_t m = std::min<size_t>(NTT_MAX_BATCH, batch - done);
@@ -2057,31 +2078,27 @@ int plk_dev_coset_ntt(plk_ctx* ctx, void* stream, const uint64_t* const* in, siz
 
 int plk_dev_quotient(plk_ctx* ctx, void* stream, const uint64_t* const* numerators, size_t count, const uint64_t alpha[4], size_t n, size_t N,
                      const uint64_t shift[4], uint64_t* coeffs_out) {
-  int rc = use_stream(ctx, (hipStream_t)stream);
-  if (rc) return rc;
+  STREAM_CALL(ctx, stream);
   return launch_quotient(ctx, (hipStream_t)stream, numerators, count, alpha, n, N, shift, coeffs_out);
 }
 
 int plk_dev_gate_table_fill(plk_ctx* ctx, void* stream, const uint8_t* row_ops, const uint64_t* const node_ids[4], size_t n,
                             const uint64_t* node_values, size_t n_values, const uint64_t default_val[4],
                             uint64_t* const wires_out[4], uint64_t* const sel_out[9]) {
-  int rc = use_stream(ctx, (hipStream_t)stream);
-  if (rc) return rc;
+  STREAM_CALL(ctx, stream);
   if (!node_ids || !wires_out) return fail(ctx, PLK_ERR_ARG, "null pointer table");
   return launch_gate_table_fill(ctx, (hipStream_t)stream, row_ops, node_ids, n, node_values, n_values, default_val, wires_out, sel_out);
 }
 
 int plk_dev_sigma_table(plk_ctx* ctx, void* stream, const uint64_t* const node_ids[4], size_t n, uint64_t* const sigma_out[4]) {
-  int rc = use_stream(ctx, (hipStream_t)stream);
-  if (rc) return rc;
+  STREAM_CALL(ctx, stream);
   if (!node_ids || !sigma_out) return fail(ctx, PLK_ERR_ARG, "null pointer table");
   return launch_sigma_table(ctx, (hipStream_t)stream, node_ids, n, sigma_out);
 }
 
 int plk_dev_gate_constraint_eval(plk_ctx* ctx, void* stream, const uint64_t* const wire_evals[4],
                                  const uint64_t* const sel_evals[9], size_t N, uint64_t* out) {
-  int rc = use_stream(ctx, (hipStream_t)stream);
-  if (rc) return rc;
+  STREAM_CALL(ctx, stream);
   if (!wire_evals) return fail(ctx, PLK_ERR_ARG, "null pointer table");
   return launch_gate_eval(ctx, (hipStream_t)stream, wire_evals, sel_evals, N, out);
 }
@@ -2089,8 +2106,7 @@ int plk_dev_gate_constraint_eval(plk_ctx* ctx, void* stream, const uint64_t* con
 int plk_dev_perm_constraint_eval(plk_ctx* ctx, void* stream, const uint64_t* z_evals, const uint64_t* const sigma_evals[4],
                                  const uint64_t* const wire_evals[4], size_t N, const uint64_t beta[4],
                                  const uint64_t gamma[4], size_t z_shift, uint64_t* out) {
-  int rc = use_stream(ctx, (hipStream_t)stream);
-  if (rc) return rc;
+  STREAM_CALL(ctx, stream);
   if (!sigma_evals || !wire_evals) return fail(ctx, PLK_ERR_ARG, "null pointer table");
   return launch_perm_eval(ctx, (hipStream_t)stream, z_evals, sigma_evals, wire_evals, N, beta, gamma, z_shift, out);
 }
@@ -2098,8 +2114,7 @@ int plk_dev_perm_constraint_eval(plk_ctx* ctx, void* stream, const uint64_t* z_e
 int plk_dev_perm_constraint_eval_range(plk_ctx* ctx, void* stream, const uint64_t* z_evals, const uint64_t* const sigma_evals[4],
                                        const uint64_t* const wire_evals[4], size_t count, size_t index0, const uint64_t beta[4],
                                        const uint64_t gamma[4], size_t z_shift, uint64_t* out) {
-  int rc = use_stream(ctx, (hipStream_t)stream);
-  if (rc) return rc;
+  STREAM_CALL(ctx, stream);
   if (!sigma_evals || !wire_evals) return fail(ctx, PLK_ERR_ARG, "null pointer table");
   return launch_perm_eval(ctx, (hipStream_t)stream, z_evals, sigma_evals, wire_evals, count, beta, gamma, z_shift, out, index0, true);
 }
@@ -2107,16 +2122,15 @@ int plk_dev_perm_constraint_eval_range(plk_ctx* ctx, void* stream, const uint64_
 int plk_dev_round23(plk_ctx* ctx, void* stream, const uint64_t* const wires[4], const uint64_t* const sel[9],
                     const uint64_t* const sigma[4], size_t n, size_t N, const uint64_t beta[4], const uint64_t gamma[4],
                     size_t z_shift, uint64_t* z_out, uint64_t* gate_out, uint64_t* perm_out) {
-  int rc = use_stream(ctx, (hipStream_t)stream);
-  if (rc) return rc;
+  STREAM_CALL(ctx, stream);
   if (!wires || !sigma) return fail(ctx, PLK_ERR_ARG, "null pointer table");
   return launch_round23(ctx, (hipStream_t)stream, wires, sel, sigma, n, N, beta, gamma, z_shift, z_out, gate_out, perm_out);
 }
 
 int plk_dev_extend4(plk_ctx* ctx, void* stream, const uint64_t* const* cols, const uint32_t* kinds, size_t batch, size_t n,
                     uint64_t* const* coef_out, uint64_t* const* eval_out, size_t chunk, size_t chunk_stride, size_t halo) {
-  int rc = use_stream(ctx, (hipStream_t)stream);
-  if (rc) return rc;
+  STREAM_CALL(ctx, stream);
+  int rc;
   if (!cols || !eval_out) return fail(ctx, PLK_ERR_ARG, "null pointer table");
   for (size_t done = 0; done < batch; done += NTT_MAX_BATCH) {
     const size_t m = std::min<size_t>(NTT_MAX_BATCH, batch - done);
@@ -2129,8 +2143,8 @@ int plk_dev_extend4(plk_ctx* ctx, void* stream, const uint64_t* const* cols, con
 
 int plk_dev_ntt_strided(plk_ctx* ctx, void* stream, const uint64_t* in, size_t in_stride, uint32_t kind, size_t count,
                         size_t n_in, size_t N, int inverse, uint64_t* out, size_t out_stride) {
-  int rc = use_stream(ctx, (hipStream_t)stream);
-  if (rc) return rc;
+  STREAM_CALL(ctx, stream);
+  int rc;
   if (count == 0) return PLK_OK;
   if (!out || (!in && n_in)) return fail(ctx, PLK_ERR_ARG, "null pointer");
   if (in_stride < n_in || out_stride < N) return fail(ctx, PLK_ERR_ARG, "stride shorter than a column");
@@ -2147,21 +2161,18 @@ int plk_dev_ntt_strided(plk_ctx* ctx, void* stream, const uint64_t* in, size_t i
 }
 
 int plk_dev_fourstep_cols(plk_ctx* ctx, void* stream, const uint64_t* recv1, size_t N, size_t ranks, size_t rank, int inverse, uint64_t* send2_out) {
-  int rc = use_stream(ctx, (hipStream_t)stream);
-  if (rc) return rc;
+  STREAM_CALL(ctx, stream);
   return launch_fs_cols(ctx, (hipStream_t)stream, recv1, N, ranks, rank, inverse != 0, send2_out);
 }
 
 int plk_dev_fourstep_rows(plk_ctx* ctx, void* stream, const uint64_t* recv2, size_t N, size_t ranks, size_t rank, int inverse, int natural_layout,
                           uint64_t* out) {
-  int rc = use_stream(ctx, (hipStream_t)stream);
-  if (rc) return rc;
+  STREAM_CALL(ctx, stream);
   return launch_fs_rows(ctx, (hipStream_t)stream, recv2, N, ranks, rank, inverse != 0, natural_layout != 0, out);
 }
 
 int plk_dev_mul(plk_ctx* ctx, void* stream, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
-  int rc = use_stream(ctx, (hipStream_t)stream);
-  if (rc) return rc;
+  STREAM_CALL(ctx, stream);
   if (n == 0) return PLK_OK;
   if (!a || !b || !out) return fail(ctx, PLK_ERR_ARG, "null pointer");
   hipLaunchKernelGGL(mul_kernel, dim3((unsigned)((n + EW_THREADS - 1) / EW_THREADS)), dim3(EW_THREADS), 0, (hipStream_t)stream,
@@ -2172,8 +2183,8 @@ int plk_dev_mul(plk_ctx* ctx, void* stream, const uint64_t* a, const uint64_t* b
 
 int plk_dev_twiddle_block(plk_ctx* ctx, void* stream, size_t N, int inverse, int scale_by_inverse_n, size_t rows, size_t cols,
                           size_t row0, size_t col0, uint64_t* out) {
-  int rc = use_stream(ctx, (hipStream_t)stream), log_n;
-  if (rc) return rc;
+  STREAM_CALL(ctx, stream);
+  int rc, log_n;
   if ((rc = check_domain(ctx, N, &log_n))) return rc;
   if (rows * cols == 0) return PLK_OK;
   if (!out) return fail(ctx, PLK_ERR_ARG, "null pointer");
@@ -2188,14 +2199,12 @@ int plk_dev_twiddle_block(plk_ctx* ctx, void* stream, size_t N, int inverse, int
 }
 
 int plk_dev_status(plk_ctx* ctx, void* stream) {
-  int rc = use_stream(ctx, (hipStream_t)stream);
-  if (rc) return rc;
+  STREAM_CALL(ctx, stream);
   return fetch_status(ctx, (hipStream_t)stream);
 }
 
 int plk_dev_to_montgomery(plk_ctx* ctx, void* stream, const uint64_t* in, size_t n, uint64_t* out) {
-  int rc = use_stream(ctx, (hipStream_t)stream);
-  if (rc) return rc;
+  STREAM_CALL(ctx, stream);
   if (n == 0) return PLK_OK;
   if (!in || !out) return fail(ctx, PLK_ERR_ARG, "null pointer");
   hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((n + EW_THREADS - 1) / EW_THREADS)), dim3(EW_THREADS), 0,
@@ -2205,8 +2214,7 @@ int plk_dev_to_montgomery(plk_ctx* ctx, void* stream, const uint64_t* in, size_t
 }
 
 int plk_dev_from_montgomery(plk_ctx* ctx, void* stream, const uint64_t* in, size_t n, uint64_t* out) {
-  int rc = use_stream(ctx, (hipStream_t)stream);
-  if (rc) return rc;
+  STREAM_CALL(ctx, stream);
   if (n == 0) return PLK_OK;
   if (!in || !out) return fail(ctx, PLK_ERR_ARG, "null pointer");
   Fe raw_one = fe_zero();
@@ -2220,8 +2228,8 @@ int plk_dev_from_montgomery(plk_ctx* ctx, void* stream, const uint64_t* in, size
 // ---------------------------------------------------------------------------- host API
 
 int plk_intt(plk_ctx* ctx, const uint64_t* evals, size_t evals_len, size_t domain_size, uint64_t* coeffs_out) {
-  int rc = use_host_stream(ctx), log_n;
-  if (rc) return rc;
+  HOST_CALL(ctx);
+  int rc, log_n;
   if ((rc = check_domain(ctx, domain_size, &log_n))) return rc;
   if (evals_len != domain_size) return fail(ctx, PLK_ERR_LENGTH, plk_strerror(PLK_ERR_LENGTH));
   if (!evals || !coeffs_out) return fail(ctx, PLK_ERR_ARG, "null pointer");
@@ -2237,8 +2245,8 @@ int plk_intt(plk_ctx* ctx, const uint64_t* evals, size_t evals_len, size_t domai
 }
 
 int plk_build_and_convert(plk_ctx* ctx, size_t domain_size, plk_builder_fn builder, void* user, uint64_t* coeffs_out) {
-  int rc = use_host_stream(ctx), log_n;
-  if (rc) return rc;
+  HOST_CALL(ctx);
+  int rc, log_n;
   if (!builder || !coeffs_out) return fail(ctx, PLK_ERR_ARG, "null pointer");
   // the domain is checked before anything is sized by it: a bogus size must come back as a code, not as an
   // exception leaving an extern "C" function
@@ -2253,8 +2261,8 @@ int plk_build_and_convert(plk_ctx* ctx, size_t domain_size, plk_builder_fn build
 }
 
 int plk_ntt(plk_ctx* ctx, const uint64_t* coeffs, size_t n_coeffs, size_t domain_size, uint64_t* evals_out) {
-  int rc = use_host_stream(ctx), log_n;
-  if (rc) return rc;
+  HOST_CALL(ctx);
+  int rc, log_n;
   if ((rc = check_domain(ctx, domain_size, &log_n))) return rc;
   if (n_coeffs > domain_size) return fail(ctx, PLK_ERR_LENGTH, "more coefficients than domain points");
   if ((!coeffs && n_coeffs) || !evals_out) return fail(ctx, PLK_ERR_ARG, "null pointer");
@@ -2272,8 +2280,8 @@ int plk_ntt(plk_ctx* ctx, const uint64_t* coeffs, size_t n_coeffs, size_t domain
 
 int plk_gate_polys(plk_ctx* ctx, const uint64_t* const wires[4], const uint64_t* const sel[9], size_t n, size_t domain_size,
                    uint64_t* const wires_out[4], uint64_t* const sel_out[9]) {
-  int rc = use_host_stream(ctx), log_n;
-  if (rc) return rc;
+  HOST_CALL(ctx);
+  int rc, log_n;
   if ((rc = check_domain(ctx, domain_size, &log_n))) return rc;
   if (n != domain_size) return fail(ctx, PLK_ERR_LENGTH, plk_strerror(PLK_ERR_LENGTH));
   if (!wires || !wires_out) return fail(ctx, PLK_ERR_ARG, "null pointer table");
@@ -2298,8 +2306,8 @@ int plk_gate_polys(plk_ctx* ctx, const uint64_t* const wires[4], const uint64_t*
 
 int plk_gate_constraints(plk_ctx* ctx, const uint64_t* const wire_coeffs[4], const uint64_t* const sel_coeffs[9], size_t n_coeffs,
                          size_t N, uint64_t* out_host) {
-  int rc = use_host_stream(ctx), log_n;
-  if (rc) return rc;
+  HOST_CALL(ctx);
+  int rc, log_n;
   if ((rc = check_domain(ctx, N, &log_n))) return rc;
   if (n_coeffs > N) return fail(ctx, PLK_ERR_LENGTH, "more coefficients than domain points");
   if (!wire_coeffs || !out_host) return fail(ctx, PLK_ERR_ARG, "null pointer");
@@ -2327,8 +2335,8 @@ int plk_gate_constraints(plk_ctx* ctx, const uint64_t* const wire_coeffs[4], con
 
 int plk_grand_product(plk_ctx* ctx, const uint64_t* const wires[4], const uint64_t* const sigma[4], size_t n,
                       const uint64_t beta[4], const uint64_t gamma[4], uint64_t* z_out) {
-  int rc = use_host_stream(ctx);
-  if (rc) return rc;
+  HOST_CALL(ctx);
+  int rc;
   if (!wires || !sigma || !z_out) return fail(ctx, PLK_ERR_ARG, "null pointer");
   Staged st(ctx);
   const uint64_t* w[4]; const uint64_t* sg[4];
@@ -2346,8 +2354,8 @@ int plk_grand_product(plk_ctx* ctx, const uint64_t* const wires[4], const uint64
 }
 
 int plk_msm_set_bases(plk_ctx* ctx, const uint64_t* bases_host, size_t n) {
-  int rc = use_host_stream(ctx);
-  if (rc) return rc;
+  HOST_CALL(ctx);
+  int rc;
   if (!bases_host && n) return fail(ctx, PLK_ERR_ARG, "null pointer");
   if (n == 0) { msm_free_table(ctx); return PLK_OK; }
   uint64_t* d = nullptr;
@@ -2360,8 +2368,8 @@ int plk_msm_set_bases(plk_ctx* ctx, const uint64_t* bases_host, size_t n) {
 }
 
 int plk_msm_g1(plk_ctx* ctx, const uint64_t* scalars_host, size_t n, uint64_t out_xy[12]) {
-  int rc = use_host_stream(ctx);
-  if (rc) return rc;
+  HOST_CALL(ctx);
+  int rc;
   if (!scalars_host && n) return fail(ctx, PLK_ERR_ARG, "null pointer");
   Staged st(ctx);
   void* d;
@@ -2390,8 +2398,8 @@ int plk_g1_sum(const uint64_t* points_xy, size_t count, uint64_t out_xy[12]) {
 }
 
 int plk_msm_g1_batch(plk_ctx* ctx, const uint64_t* const scalars_host[], size_t count, size_t n, uint64_t* out_xy) {
-  int rc = use_host_stream(ctx);
-  if (rc) return rc;
+  HOST_CALL(ctx);
+  int rc;
   if (!scalars_host && count) return fail(ctx, PLK_ERR_ARG, "null pointer");
   Staged st(ctx);
   std::vector<const uint64_t*> d(count);
@@ -2405,8 +2413,8 @@ int plk_msm_g1_batch(plk_ctx* ctx, const uint64_t* const scalars_host[], size_t 
 }
 
 int plk_coset_ntt(plk_ctx* ctx, const uint64_t* in, size_t n_in, size_t domain_size, const uint64_t shift[4], int inverse, uint64_t* out) {
-  int rc = use_host_stream(ctx);
-  if (rc) return rc;
+  HOST_CALL(ctx);
+  int rc;
   if ((!in && n_in) || !out) return fail(ctx, PLK_ERR_ARG, "null pointer");
   Staged st(ctx);
   void *d_in, *d_out;
@@ -2422,8 +2430,8 @@ int plk_coset_ntt(plk_ctx* ctx, const uint64_t* in, size_t n_in, size_t domain_s
 
 int plk_quotient(plk_ctx* ctx, const uint64_t* const* numerators, size_t count, const uint64_t alpha[4], size_t n, size_t N,
                  const uint64_t shift[4], uint64_t* coeffs_out) {
-  int rc = use_host_stream(ctx);
-  if (rc) return rc;
+  HOST_CALL(ctx);
+  int rc;
   if (!numerators || !coeffs_out) return fail(ctx, PLK_ERR_ARG, "null pointer");
   if (count == 0 || count > QT_MAX_NUMERATORS) return fail(ctx, PLK_ERR_ARG, "between 1 and 8 numerators");
   Staged st(ctx);
@@ -2444,8 +2452,8 @@ int plk_quotient(plk_ctx* ctx, const uint64_t* const* numerators, size_t count, 
 int plk_gate_table_fill(plk_ctx* ctx, const uint8_t* row_ops, const uint64_t* const node_ids[4], size_t n,
                         const uint64_t* node_values, size_t n_values, const uint64_t default_val[4],
                         uint64_t* const wires_out[4], uint64_t* const sel_out[9]) {
-  int rc = use_host_stream(ctx);
-  if (rc) return rc;
+  HOST_CALL(ctx);
+  int rc;
   if (!node_ids || !wires_out) return fail(ctx, PLK_ERR_ARG, "null pointer");
   if (n == 0) return PLK_OK;
   if (!row_ops) return fail(ctx, PLK_ERR_ARG, "null pointer");
@@ -2471,8 +2479,8 @@ int plk_gate_table_fill(plk_ctx* ctx, const uint8_t* row_ops, const uint64_t* co
 }
 
 int plk_sigma_table(plk_ctx* ctx, const uint64_t* const node_ids[4], size_t n, uint64_t* const sigma_out[4]) {
-  int rc = use_host_stream(ctx);
-  if (rc) return rc;
+  HOST_CALL(ctx);
+  int rc;
   if (!node_ids || !sigma_out) return fail(ctx, PLK_ERR_ARG, "null pointer");
   if (n == 0) return PLK_OK;
   Staged st(ctx);
@@ -2491,8 +2499,8 @@ int plk_sigma_table(plk_ctx* ctx, const uint64_t* const node_ids[4], size_t n, u
 int plk_perm_polys(plk_ctx* ctx, const uint64_t* const wires[4], const uint64_t* const sigma[4], size_t n, size_t domain_size,
                    const uint64_t beta[4], const uint64_t gamma[4], uint64_t* const sigma_coeffs_out[4], uint64_t* z_coeffs_out,
                    uint64_t* z_last_out) {
-  int rc = use_host_stream(ctx), log_n;
-  if (rc) return rc;
+  HOST_CALL(ctx);
+  int rc, log_n;
   if ((rc = check_domain(ctx, domain_size, &log_n))) return rc;
   if (n != domain_size) return fail(ctx, PLK_ERR_LENGTH, plk_strerror(PLK_ERR_LENGTH));
   if (!wires || !sigma || !sigma_coeffs_out || !z_coeffs_out) return fail(ctx, PLK_ERR_ARG, "null pointer");
@@ -2523,8 +2531,8 @@ int plk_perm_polys(plk_ctx* ctx, const uint64_t* const wires[4], const uint64_t*
 int plk_perm_constraints(plk_ctx* ctx, const uint64_t* z_coeffs, const uint64_t* const sigma_coeffs[4],
                          const uint64_t* const wire_coeffs[4], size_t n_coeffs, size_t N, const uint64_t beta[4],
                          const uint64_t gamma[4], size_t z_shift, uint64_t* out_host) {
-  int rc = use_host_stream(ctx), log_n;
-  if (rc) return rc;
+  HOST_CALL(ctx);
+  int rc, log_n;
   if ((rc = check_domain(ctx, N, &log_n))) return rc;
   if (n_coeffs > N) return fail(ctx, PLK_ERR_LENGTH, "more coefficients than domain points");
   if (!sigma_coeffs || !wire_coeffs || !out_host || (!z_coeffs && n_coeffs)) return fail(ctx, PLK_ERR_ARG, "null pointer");
@@ -2550,8 +2558,8 @@ int plk_perm_constraints(plk_ctx* ctx, const uint64_t* z_coeffs, const uint64_t*
 int plk_round23(plk_ctx* ctx, const uint64_t* const wires[4], const uint64_t* const sel[9], const uint64_t* const sigma[4], size_t n,
                 size_t N, const uint64_t beta[4], const uint64_t gamma[4], size_t z_shift, uint64_t* z_out, uint64_t* gate_out,
                 uint64_t* perm_out) {
-  int rc = use_host_stream(ctx), l1, l2;
-  if (rc) return rc;
+  HOST_CALL(ctx);
+  int rc, l1, l2;
   if ((rc = check_domain(ctx, n, &l1))) return rc;
   if ((rc = check_domain(ctx, N, &l2))) return rc;
   if (!wires || !sigma || !beta || !gamma) return fail(ctx, PLK_ERR_ARG, "null pointer");

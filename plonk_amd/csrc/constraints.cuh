@@ -216,6 +216,12 @@ __global__ __launch_bounds__(EW_THREADS) void index_to_field_kernel(const uint64
 }
 
 // out[i] = in[i] * factor  (Montgomery <-> canonical conversion helpers: factor = R^2 or 1)
+// out[i] = v, i < n
+__global__ void fe_fill_kernel(uint64_t* out, uint64_t n, Fe v) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) fe_store(out, i, v);
+}
+
 __global__ __launch_bounds__(EW_THREADS) void scale_kernel(const uint64_t* in, uint64_t n, Fe factor, uint64_t* out) {
   const uint64_t i = (uint64_t)blockIdx.x * EW_THREADS + threadIdx.x;
   if (i >= n) return;

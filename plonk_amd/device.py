@@ -52,12 +52,17 @@ class DeviceCircuit:
     beta: np.ndarray
     gamma: np.ndarray
     _tabs: Optional[tuple] = None
+    _tab_ptrs: Optional[tuple] = None
 
     def tables(self):
-        """(wires, selectors, sigma) pointer tables, built on first use: the columns of an uploaded circuit stay where
-        they are (beta and gamma may be replaced at will, they are passed by value each call)."""
-        if self._tabs is None:
-            self._tabs = (_table(self.wires), _table([self.selectors.get(k) for k in AST_KINDS]), _table(self.sigma))
+        """(wires, selectors, sigma) pointer tables, rebuilt only when a column has been rebound to another tensor
+        (17 addresses compared per call; a cast per pointer per call is what a small circuit's call would otherwise
+        spend most of its time on).  beta and gamma may be replaced at will, they are passed by value each call."""
+        sels = [self.selectors.get(k) for k in AST_KINDS]
+        ptrs = tuple(t.data_ptr() if t is not None else 0 for t in (*self.wires, *sels, *self.sigma))
+        if self._tabs is None or ptrs != self._tab_ptrs:
+            self._tabs = (_table(self.wires), _table(sels), _table(self.sigma))
+            self._tab_ptrs = ptrs
         return self._tabs
 
 

@@ -107,16 +107,34 @@ unsafe impl Send for Ctx {}
 /// re-entrant and callers may use any thread.
 static CTX: Mutex<Option<Ctx>> = Mutex::new(None);
 
-fn with_ctx<R>(f: impl FnOnce(*mut sys::plk_ctx) -> R) -> R {
-    let mut guard = CTX.lock().unwrap();
-    if guard.is_none() {
-        let device = std::env::var("PLONK_HIP_DEVICE").ok().and_then(|s| s.parse().ok()).unwrap_or(0);
-        let mut p: *mut sys::plk_ctx = ptr::null_mut();
-        let rc = unsafe { sys::plk_ctx_create(device, &mut p) };
-        assert_eq!(rc, sys::PLK_OK, "plk_ctx_create(device = {}) failed: {}", device, strerror(rc));
-        *guard = Some(Ctx(p));
+/// Runs `f` on the context under the lock.  `f` reports a failure as the text of the panic the reference would
+/// raise (`check` builds it, reading the context's error string and row while the lock is still held); the panic
+/// itself is raised here AFTER the guard has been dropped, so the reference's ordinary, recoverable panics (a
+/// zero denominator, a sigma index, a length: `catch_unwind`, `#[should_panic]` tests sharing one binary) never
+/// poison the lock.  A lock poisoned by a panic in the caller's own closure (`build_and_convert`'s builder) is
+/// taken over all the same: the C context stays valid after any error return.
+fn with_ctx(f: impl FnOnce(*mut sys::plk_ctx) -> Result<(), String>) {
+    let failure = {
+        let mut guard = CTX.lock().unwrap_or_else(|e| e.into_inner());
+        let mut create_failure = None;
+        if guard.is_none() {
+            let device = std::env::var("PLONK_HIP_DEVICE").ok().and_then(|s| s.parse().ok()).unwrap_or(0);
+            let mut p: *mut sys::plk_ctx = ptr::null_mut();
+            let rc = unsafe { sys::plk_ctx_create(device, &mut p) };
+            if rc == sys::PLK_OK {
+                *guard = Some(Ctx(p));
+            } else {
+                create_failure = Some(format!("plk_ctx_create(device = {}) failed: {}", device, strerror(rc)));
+            }
+        }
+        match create_failure {
+            Some(msg) => Err(msg),
+            None => f(guard.as_ref().unwrap().0),
+        }
+    }; // the guard is gone here
+    if let Err(msg) = failure {
+        panic!("{}", msg);
     }
-    f(guard.as_ref().unwrap().0)
 }
 
 fn strerror(rc: i32) -> String {
@@ -128,20 +146,21 @@ fn last_error(ctx: *mut sys::plk_ctx, rc: i32) -> String {
     if s.is_empty() { strerror(rc) } else { s }
 }
 
-/// Turns a status code back into the panic the reference raises at the cited line.
-fn check(ctx: *mut sys::plk_ctx, rc: i32, length_message: &str) {
+/// Turns a status code into the text of the panic the reference raises at the cited line (`with_ctx` raises it
+/// once the lock is released).
+fn check(ctx: *mut sys::plk_ctx, rc: i32, length_message: &str) -> Result<(), String> {
     match rc {
-        sys::PLK_OK => {}
+        sys::PLK_OK => Ok(()),
         // assert_eq! on lengths, src/polynomial_utils.rs:22-26 and :56-60
-        sys::PLK_ERR_LENGTH => panic!("assertion failed: `(left == right)`: {}", length_message),
+        sys::PLK_ERR_LENGTH => Err(format!("assertion failed: `(left == right)`: {}", length_message)),
         // `denominator.inverse().unwrap()`, src/permutation_polynomial.rs:258
-        sys::PLK_ERR_ZERO_DENOMINATOR => panic!(
+        sys::PLK_ERR_ZERO_DENOMINATOR => Err(format!(
             "called `Option::unwrap()` on a `None` value (zero denominator at row {})",
             unsafe { sys::plk_last_error_row(ctx) }
-        ),
+        )),
         // slice index, src/permutation_polynomial.rs:235-238
-        sys::PLK_ERR_SIGMA_RANGE => panic!("index out of bounds (sigma at row {})", unsafe { sys::plk_last_error_row(ctx) }),
-        _ => panic!("libplonk_hip: {}", last_error(ctx, rc)),
+        sys::PLK_ERR_SIGMA_RANGE => Err(format!("index out of bounds (sigma at row {})", unsafe { sys::plk_last_error_row(ctx) })),
+        _ => Err(format!("libplonk_hip: {}", last_error(ctx, rc))),
     }
 }
 
@@ -188,7 +207,7 @@ pub fn evaluations_to_dense_polynomial<F: FftField>(evals: &[F], domain: &Genera
     let mut coeffs = vec![F::zero(); domain.size()];
     with_ctx(|ctx| {
         let rc = unsafe { sys::plk_intt(ctx, limbs(evals), evals.len(), domain.size(), limbs_mut(&mut coeffs)) };
-        check(ctx, rc, "Evaluation length must match the domain size");
+        check(ctx, rc, "Evaluation length must match the domain size")
     });
     DensePolynomial::from_coefficients_vec(coeffs) // drops trailing zero coefficients exactly as at :32
 }
@@ -233,7 +252,7 @@ pub fn gate_evaluation_table_to_gate_polynomial<F: FftField>(
             sel_out.iter_mut().map(|o| o.as_mut().map_or(ptr::null_mut(), |v| limbs_mut(v))).collect();
         with_ctx(|ctx| {
             let rc = unsafe { sys::plk_gate_polys(ctx, wires.as_ptr(), sel.as_ptr(), n, n, wire_out_ptrs.as_ptr(), sel_out_ptrs.as_ptr()) };
-            check(ctx, rc, "Evaluation length must match the domain size");
+            check(ctx, rc, "Evaluation length must match the domain size")
         });
     }
     let mut selectors = HashMap::new();
@@ -269,7 +288,7 @@ pub fn build_gate_constraint_evaluation_polynomial<F: FftField>(gate_poly: &Gate
     with_ctx(|ctx| {
         // more coefficients than domain points is the length panic inside evaluate_over_domain_by_ref
         let rc = unsafe { sys::plk_gate_constraints(ctx, wires.as_ptr(), sel.as_ptr(), n_coeffs, big_n, limbs_mut(&mut out)) };
-        check(ctx, rc, "polynomial degree exceeds the evaluation domain");
+        check(ctx, rc, "polynomial degree exceeds the evaluation domain")
     });
     out
 }
@@ -296,7 +315,7 @@ pub fn build_grand_product_evaluation_polynomial<F: Field>(
     let mut z = vec![F::one(); n + 1];
     with_ctx(|ctx| {
         let rc = unsafe { sys::plk_grand_product(ctx, wires.as_ptr(), sigma.as_ptr(), n, one_elem(&beta), one_elem(&gamma), limbs_mut(&mut z)) };
-        check(ctx, rc, "");
+        check(ctx, rc, "")
     });
     z
 }
@@ -340,7 +359,7 @@ pub fn build_permutation_polynomials_with_last<F: FftField>(
                 sys::plk_perm_polys(ctx, wires.as_ptr(), sigma.as_ptr(), n, n, one_elem(&beta), one_elem(&gamma), sig_ptrs.as_ptr(),
                                     limbs_mut(&mut z_coeffs), &mut z_last as *mut F as *mut u64)
             };
-            check(ctx, rc, "Evaluation length must match the domain size");
+            check(ctx, rc, "Evaluation length must match the domain size")
         });
     }
     let mut it = sig_out.into_iter().map(DensePolynomial::from_coefficients_vec);
@@ -378,7 +397,7 @@ pub fn build_permutation_constraint_evaluation_polynomial<F: FftField>(
             sys::plk_perm_constraints(ctx, limbs(&z), sig_ptrs.as_ptr(), wir_ptrs.as_ptr(), n_coeffs, big_n, one_elem(&beta), one_elem(&gamma), 1,
                                       limbs_mut(&mut out))
         };
-        check(ctx, rc, "polynomial degree exceeds the evaluation domain");
+        check(ctx, rc, "polynomial degree exceeds the evaluation domain")
     });
     out
 }
@@ -419,7 +438,7 @@ pub fn prove_round23<F: FftField>(
             sys::plk_round23(ctx, wires.as_ptr(), sel.as_ptr(), sigma.as_ptr(), n, big_n, one_elem(&beta), one_elem(&gamma), 1,
                              limbs_mut(&mut z), limbs_mut(&mut gate), limbs_mut(&mut perm))
         };
-        check(ctx, rc, "Evaluation length must match the domain size");
+        check(ctx, rc, "Evaluation length must match the domain size")
     });
     (z, gate, perm)
 }

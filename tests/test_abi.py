@@ -57,3 +57,13 @@ def test_product_path_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".cuh", ".cpp", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "plonk_oracle" not in src and "c_oracle" not in src and "liboracle" not in src, f
+
+
+def test_limits_in_the_binding_are_the_header_s():
+    """Numbers the Python binding repeats from plonk_hip.h (the library ties its own copies to the header with
+    static_asserts)."""
+    text = open(os.path.join(ROOT, "include", "plonk_hip.h")).read()
+    shift = int(re.search(r"#define PLK_NOALLOC_MAX_ROWS \(\(size_t\)1 << (\d+)\)", text).group(1))
+    assert _lib.NOALLOC_MAX_ROWS == 1 << shift
+    assert _lib.MAX_BATCH == int(re.search(r"#define PLK_MAX_BATCH (\d+)", text).group(1))
+    assert _lib.NUM_SELECTORS == int(re.search(r"#define PLK_NUM_SELECTORS (\d+)", text).group(1))

@@ -128,3 +128,25 @@ def test_randomised_sweep(prover):
         outs = prover.round23(prover.upload(c), N, z_shift=z_shift)
         prover.status()
         assert _same(outs, _oracle(c, N, c.beta, c.gamma, z_shift=z_shift)), (case, log_n, N // n, kinds, z_shift)
+
+
+def test_rebinding_a_column_is_seen_by_round23(prover):
+    """The driver caches its pointer tables per uploaded circuit; a column bound to another tensor afterwards must reach
+    every entry point, the cached ones included."""
+    import torch
+    from plonk_amd import synth
+    n, N = 1 << 8, 1 << 10
+    a, b = synth.make_circuit(n, circuit_id=31), synth.make_circuit(n, circuit_id=32)
+    da, db = prover.upload(a), prover.upload(b)
+    za = prover.round23(da, N)
+    want = [t.clone() for t in prover.round23(db, N)]
+    # turn `da` into circuit b by rebinding (not overwriting) its columns
+    da.wires[:] = db.wires
+    da.sigma[:] = db.sigma
+    for k in list(da.selectors):
+        da.selectors[k] = db.selectors[k]
+    da.beta, da.gamma = db.beta, db.gamma
+    got = prover.round23(da, N)
+    prover.status()
+    assert all(torch.equal(x, y) for x, y in zip(got, want))
+    assert not torch.equal(za[0], want[0])

@@ -86,3 +86,33 @@ def test_build_and_convert_rejects_a_bogus_domain_before_sizing_anything(ctx):
     for size, code in ((1 << 40, _lib.PLK_ERR_TWO_ADICITY), ((1 << 62) + 1, _lib.PLK_ERR_NOT_POW2)):
         rc = ctx.lib.plk_build_and_convert(ctx.handle, size, fn, None, small.ctypes.data_as(_lib.u64p))
         assert rc == code and not called
+
+
+def test_a_stream_may_be_destroyed_between_calls(prover):
+    """A caller with one stream per request: create a stream, enqueue a call, wait for it, destroy the stream - and the
+    next call, on another stream, must not touch the dead handle (the library records its ordering event on a call's
+    own stream at the end of that call, never on the previous call's stream)."""
+    import ctypes as C
+    from plonk_amd.device import _table, _ptr
+    hip = C.CDLL("libamdhip64.so")        # already mapped by torch / the library: the same runtime
+    n = 1 << 12
+    c = synth.make_circuit(n, circuit_id=24)
+    dc = prover.upload(c)
+    want = prover.grand_product(dc)
+    prover.status()
+    torch.cuda.synchronize()
+    b, g = dc.beta.ctypes.data_as(_lib.u64p), dc.gamma.ctypes.data_as(_lib.u64p)
+    for _ in range(3):
+        st = C.c_void_p()
+        assert hip.hipStreamCreate(C.byref(st)) == 0
+        z = prover.empty(n + 1)
+        torch.cuda.synchronize()            # (the tensor's allocation is not stream-ordered against a raw stream)
+        rc = prover.lib.plk_dev_grand_product(prover.ctx.handle, st, _table(dc.wires), _table(dc.sigma), n, b, g, _ptr(z))
+        prover.ctx.check(rc)
+        assert hip.hipStreamSynchronize(st) == 0
+        assert hip.hipStreamDestroy(st) == 0
+        assert torch.equal(z, want)
+        # the next call comes on torch's stream: the destroyed handle must not be used again
+        z2 = prover.grand_product(dc)
+        prover.status()
+        assert torch.equal(z2, want)

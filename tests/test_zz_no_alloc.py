@@ -67,3 +67,37 @@ def test_noalloc_reports_zero_denominator(prover):
     with pytest.raises(pa.ZeroDenominator) as ei:
         prover.status()
     assert ei.value.row == 5
+
+
+def test_noalloc_under_graph_capture(prover):
+    """The call recorded into a HIP graph and replayed: nothing in it allocates, synchronises or reads host memory at
+    replay time, and a replay on changed column contents gives that data's grand product."""
+    n = 1 << 14
+    c = synth.make_circuit(n, circuit_id=18)
+    dc = prover.upload(c)
+    got = prover.empty(n + 1)
+    got.fill_(-1)
+    prover.grand_product_noalloc(dc, got)              # once outside the capture (kernels loaded, result known)
+    prover.status()
+    want = got.clone()
+    got.fill_(-1)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        prover.grand_product_noalloc(dc, got)
+    torch.cuda.synchronize()
+    assert int(got[0, 0]) == -1                        # captured, not run
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    # other data in the same buffers, same graph
+    c2 = synth.make_circuit(n, circuit_id=19)
+    for dst, src in zip(dc.wires, c2.table.wires()):
+        dst.copy_(torch.from_numpy(src.view(np.int64)))
+    for dst, src in zip(dc.sigma, c2.perm.columns()):
+        dst.copy_(torch.from_numpy(src.view(np.int64)))
+    graph.replay()
+    torch.cuda.synchronize()
+    z_ref = co.grand_product(c2.table.wires(), c2.perm.columns(), c.beta, c.gamma)   # (beta, gamma are baked into the graph)
+    assert np.array_equal(to_host(got), z_ref)
+    # the context is in order after the capture: an ordinary call on the ordinary stream
+    _both(prover, 1 << 9, circuit_id=20)
