@@ -387,6 +387,72 @@ const char* plk_profile_end(plk_ctx* ctx);
 int plk_dev_to_montgomery(plk_ctx* ctx, void* stream, const uint64_t* in, size_t n, uint64_t* out);
 int plk_dev_from_montgomery(plk_ctx* ctx, void* stream, const uint64_t* in, size_t n, uint64_t* out);
 
+/* ---- device memory for callers without a HIP binding (a Rust or C host that uses the plk_dev_* calls) ---------- */
+
+/* `bytes` of memory on the context's GPU (hipMalloc), to be released with plk_dev_free.  No counterpart in the
+ * reference, whose vectors live in host memory. */
+int plk_dev_alloc(plk_ctx* ctx, size_t bytes, void** out);
+void plk_dev_free(plk_ctx* ctx, void* p);
+/* Copies between host memory and the context's GPU, ordered on `stream` like every other device call; the call
+ * returns when the host buffer may be reused (upload) or holds the data (download).  Large pageable buffers go
+ * through the context's threaded staging copy. */
+int plk_dev_upload(plk_ctx* ctx, void* stream, void* dst_dev, const void* src_host, size_t bytes);
+int plk_dev_download(plk_ctx* ctx, void* stream, void* dst_host, const void* src_dev, size_t bytes);
+/* the context's own stream (what the host entry points enqueue on), for callers that have no stream of their own */
+void* plk_ctx_stream(plk_ctx* ctx);
+
+/* ---- one node: G ranks in ONE process, one GPU each ------------------------------------------------------------
+ *
+ * No counterpart in the reference (ark-poly runs one shared-memory FFT; nothing in the reference is distributed).
+ * A node owns one context, one stream and one host thread per rank.  The ranks exchange data either by RCCL
+ * (ncclAllToAll on communicators from ncclCommInitAll: one GPU per rank, the production form on an 8 x MI355X
+ * node, one message per peer = one per xGMI link) or by device-to-device copies on the ranks' streams ordered by
+ * events (PLK_NODE_COPY: peer copies between GPUs with peer access, plain copies when several ranks are given the
+ * SAME device - which is how the index bookkeeping of G = 2, 4, 8 ranks is rehearsed on one GPU).
+ * RCCL is bound at run time (dlopen of librccl.so.1) when a node asks for it: a process that never creates an
+ * RCCL node does not load it, and a process that already holds a copy (PyTorch ships its own) uses that one. */
+typedef struct plk_node plk_node;
+enum { PLK_NODE_RCCL = 0, PLK_NODE_COPY = 1 };
+
+/* devices[g] = GPU of rank g (G a power of two, 1 <= G <= 64).  PLK_NODE_RCCL needs G different devices. */
+int plk_node_create(const int* devices, size_t G, int exchange, plk_node** out);
+void plk_node_destroy(plk_node* node);
+size_t plk_node_ranks(const plk_node* node);
+/* rank g's context (owned by the node): for plk_dev_alloc / plk_dev_upload / plk_dev_* calls on that rank's GPU */
+plk_ctx* plk_node_ctx(plk_node* node, size_t g);
+/* text of the node's last failure ("" if none) */
+const char* plk_node_last_error(const plk_node* node);
+
+/* ONE transform of N points over the node's G ranks (four-step form: plk_dev_fourstep_cols / _rows on every rank
+ * and three all-to-all exchanges; src/polynomial_utils.rs:29 and src/execution_trace.rs:362-370 at a size one GPU
+ * is not asked to hold).  in_shards[g] / out_shards[g]: N / G elements on rank g's GPU.  Input sharded
+ * contiguously by index: rank g holds elements [g N / G, (g + 1) N / G).  Output, natural_output != 0: the same
+ * ranges of the result (natural order in and out); natural_output == 0: rank g holds the block
+ * [k1 local][k2] = X[(g r1 + k1 local) + N1 k2] (r1 = N1 / G, N1 = 2^ceil(log2(N) / 2)), saving the third exchange.
+ * inverse != 0: inverse transform including 1 / N.  out_shards[g] must not alias in_shards[g].
+ * The call returns when the work is enqueued on the ranks' streams; plk_node_sync waits for it.  Constraints as
+ * for plk_dev_fourstep_cols (G divides both sides of the N1 x N2 view, enough columns per rank). */
+int plk_node_ntt(plk_node* node, const uint64_t* const* in_shards, size_t N, int inverse, int natural_output,
+                 uint64_t* const* out_shards);
+/* The same transform on host arrays (N elements each, natural order in and out): shards go up to the ranks, the
+ * transform runs, the result comes back; returns when `out` is complete. */
+int plk_node_ntt_host(plk_node* node, const uint64_t* in, size_t N, int inverse, uint64_t* out);
+/* waits for everything the node has enqueued on every rank */
+int plk_node_sync(plk_node* node);
+
+/* Batched proofs (replicas only, no exchange): `count` independent circuits of n rows, circuit i on rank i % G with
+ * ALL its pointers in that rank's GPU memory; every rank runs plk_dev_round23 on its circuits one after another.
+ * Returns when every circuit is done: PLK_OK, or the code of the first circuit (lowest index) that failed, with
+ * plk_node_last_error naming it. */
+typedef struct {
+  const uint64_t* wires[PLK_NUM_WIRES];
+  const uint64_t* sel[PLK_NUM_SELECTORS];     /* NULL = selector absent */
+  const uint64_t* sigma[PLK_NUM_WIRES];
+  uint64_t beta[4], gamma[4];
+  uint64_t *z_out, *gate_out, *perm_out;      /* n + 1, N, N elements; gate_out / perm_out may be NULL */
+} plk_circuit_io;
+int plk_node_round23_batch(plk_node* node, const plk_circuit_io* circuits, size_t count, size_t n, size_t N, size_t z_shift);
+
 #ifdef __cplusplus
 }
 #endif

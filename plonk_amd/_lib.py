@@ -37,6 +37,17 @@ u32p = C.POINTER(C.c_uint32)
 u8p = C.POINTER(C.c_uint8)
 BUILDER_FN = C.CFUNCTYPE(C.c_size_t, C.c_void_p, u64p, C.c_size_t)
 
+NODE_RCCL = 0
+NODE_COPY = 1
+
+
+class CircuitIO(C.Structure):
+    """plk_circuit_io: the columns and outputs of one circuit of plk_node_round23_batch (device addresses)."""
+    _fields_ = [("wires", C.c_void_p * NUM_WIRES), ("sel", C.c_void_p * NUM_SELECTORS), ("sigma", C.c_void_p * NUM_WIRES),
+                ("beta", C.c_uint64 * 4), ("gamma", C.c_uint64 * 4),
+                ("z_out", C.c_void_p), ("gate_out", C.c_void_p), ("perm_out", C.c_void_p)]
+
+
 #: every symbol include/plonk_hip.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "plk_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
@@ -93,6 +104,20 @@ SIGNATURES = {
     "plk_dev_status": (C.c_int, [C.c_void_p, C.c_void_p]),
     "plk_profile_begin": (None, [C.c_void_p]),
     "plk_profile_end": (C.c_char_p, [C.c_void_p]),
+    "plk_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "plk_dev_free": (None, [C.c_void_p, C.c_void_p]),
+    "plk_dev_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "plk_dev_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "plk_ctx_stream": (C.c_void_p, [C.c_void_p]),
+    "plk_node_create": (C.c_int, [C.POINTER(C.c_int), C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]),
+    "plk_node_destroy": (None, [C.c_void_p]),
+    "plk_node_ranks": (C.c_size_t, [C.c_void_p]),
+    "plk_node_ctx": (C.c_void_p, [C.c_void_p, C.c_size_t]),
+    "plk_node_last_error": (C.c_char_p, [C.c_void_p]),
+    "plk_node_ntt": (C.c_int, [C.c_void_p, u64pp, C.c_size_t, C.c_int, C.c_int, u64pp]),
+    "plk_node_ntt_host": (C.c_int, [C.c_void_p, u64p, C.c_size_t, C.c_int, u64p]),
+    "plk_node_sync": (C.c_int, [C.c_void_p]),
+    "plk_node_round23_batch": (C.c_int, [C.c_void_p, C.POINTER(CircuitIO), C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t]),
     "plk_dev_to_montgomery": (C.c_int, [C.c_void_p, C.c_void_p, u64p, C.c_size_t, u64p]),
     "plk_dev_from_montgomery": (C.c_int, [C.c_void_p, C.c_void_p, u64p, C.c_size_t, u64p]),
 }

@@ -1941,6 +1941,54 @@ void plk_field_constants(uint64_t modulus[4], uint64_t one[4], uint64_t r2[4]) {
   }
 }
 
+
+// ---------------------------------------------------------------------------- device memory for callers without HIP
+
+int plk_dev_alloc(plk_ctx* ctx, size_t bytes, void** out) {
+  int rc = use_device(ctx);
+  if (rc) return rc;
+  if (!out) return fail(ctx, PLK_ERR_ARG, "null pointer");
+  *out = nullptr;
+  HIP_TRY(ctx, hipMalloc(out, std::max<size_t>(bytes, 256)));
+  return PLK_OK;
+}
+
+void plk_dev_free(plk_ctx* ctx, void* p) {
+  if (!ctx || !p) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipFree(p);          // (waits for the device: nothing enqueued can still use the block)
+}
+
+void* plk_ctx_stream(plk_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int plk_dev_upload(plk_ctx* ctx, void* stream, void* dst_dev, const void* src_host, size_t bytes) {
+  STREAM_CALL(ctx, stream);
+  if (bytes == 0) return PLK_OK;
+  if (!dst_dev || !src_host) return fail(ctx, PLK_ERR_ARG, "null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  if (bytes >= COPY_MIN && host_is_pageable(src_host)) {
+    HIP_TRY(ctx, hipStreamSynchronize(s));            // the threaded copy runs on streams of its own
+    return threaded_copy(ctx, dst_dev, src_host, bytes, true);
+  }
+  HIP_TRY(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  return PLK_OK;
+}
+
+int plk_dev_download(plk_ctx* ctx, void* stream, void* dst_host, const void* src_dev, size_t bytes) {
+  STREAM_CALL(ctx, stream);
+  if (bytes == 0) return PLK_OK;
+  if (!dst_host || !src_dev) return fail(ctx, PLK_ERR_ARG, "null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  if (bytes >= COPY_MIN && host_is_pageable(dst_host)) {
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return threaded_copy(ctx, dst_host, src_dev, bytes, false);
+  }
+  HIP_TRY(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  return PLK_OK;
+}
+
 // ---------------------------------------------------------------------------- profiling
 
 void plk_profile_begin(plk_ctx* ctx) {

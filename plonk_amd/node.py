@@ -1,0 +1,95 @@
+"""One node = G ranks in ONE process, one GPU each: the library's native multi-GPU entry points (`plk_node_*` in
+include/plonk_hip.h).  Where `plonk_amd.dist` runs one process per GPU and exchanges through torch.distributed, this
+form needs neither Python nor torch - a C or Rust host calls the same symbols; the wrapper here exists for the tests and
+the benchmark, with torch tensors standing in for device memory.
+
+The reference has no distributed code of any kind (src/polynomial_utils.rs:29 is one shared-memory transform)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .api import AST_KINDS, PlonkError
+from .device import DeviceCircuit, _table
+
+
+class Node:
+    """`exchange`: "rccl" (one GPU per rank, ncclAllToAll) or "copy" (device-to-device copies; several ranks may share
+    a GPU, which is how the sharded paths are rehearsed on a single GPU)."""
+
+    def __init__(self, devices: Sequence[int], exchange: str = "rccl"):
+        self.lib = _lib.load()
+        self.devices = list(devices)
+        arr = (C.c_int * len(self.devices))(*self.devices)
+        h = C.c_void_p()
+        mode = {"rccl": _lib.NODE_RCCL, "copy": _lib.NODE_COPY}[exchange]
+        rc = self.lib.plk_node_create(arr, len(self.devices), mode, C.byref(h))
+        if rc != _lib.PLK_OK:
+            raise PlonkError(rc, f"plk_node_create(devices={self.devices}, exchange={exchange}): {self.lib.plk_strerror(rc).decode()}")
+        self.handle = h
+        self.G = len(self.devices)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.plk_node_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc: int):
+        if rc != _lib.PLK_OK:
+            msg = self.lib.plk_node_last_error(self.handle).decode() or self.lib.plk_strerror(rc).decode()
+            raise PlonkError(rc, msg)
+
+    def device(self, g: int) -> torch.device:
+        return torch.device("cuda", self.devices[g])
+
+    def sync(self):
+        self.check(self.lib.plk_node_sync(self.handle))
+
+    def ntt(self, shards: Sequence[torch.Tensor], N: int, inverse: bool = False, natural_output: bool = True,
+            out: Optional[Sequence[torch.Tensor]] = None) -> List[torch.Tensor]:
+        """One transform of N points; shards[g] is rank g's `(N / G, 4) int64` tensor on its GPU, complete before the
+        call (the ranks' streams know nothing of torch's).  Returns the output shards; wait with `sync()`."""
+        out = [torch.empty_like(s) for s in shards] if out is None else list(out)
+        for g, s in enumerate(shards):
+            torch.cuda.synchronize(s.device)
+        self.check(self.lib.plk_node_ntt(self.handle, _table(shards), N, 1 if inverse else 0, 1 if natural_output else 0, _table(out)))
+        return out
+
+    def ntt_host(self, x: np.ndarray, inverse: bool = False) -> np.ndarray:
+        """The transform of a host array `(N, 4) uint64`, natural order in and out."""
+        x = np.ascontiguousarray(x, dtype=np.uint64)
+        out = np.empty_like(x)
+        self.check(self.lib.plk_node_ntt_host(self.handle, x.ctypes.data_as(_lib.u64p), x.shape[0], 1 if inverse else 0,
+                                              out.ctypes.data_as(_lib.u64p)))
+        return out
+
+    def round23_batch(self, circuits: Sequence[DeviceCircuit], N: int, outs, z_shift: int = 1):
+        """Rounds 2+3 of `circuits[i]` (resident on rank i % G's GPU) into `outs[i] = (z, gate, perm)` tensors on the
+        same GPU; returns when all are done."""
+        n = circuits[0].n
+        arr = (_lib.CircuitIO * len(circuits))()
+        for io, dc, (z, g, p) in zip(arr, circuits, outs):
+            for k in range(4):
+                io.wires[k] = dc.wires[k].data_ptr()
+                io.sigma[k] = dc.sigma[k].data_ptr()
+            for k, kind in enumerate(AST_KINDS):
+                t = dc.selectors.get(kind)
+                io.sel[k] = t.data_ptr() if t is not None else None
+            for k in range(4):
+                io.beta[k] = int(dc.beta[k])
+                io.gamma[k] = int(dc.gamma[k])
+            io.z_out, io.gate_out, io.perm_out = z.data_ptr(), g.data_ptr(), p.data_ptr()
+        for d in set(self.devices):
+            torch.cuda.synchronize(d)
+        self.check(self.lib.plk_node_round23_batch(self.handle, arr, len(circuits), n, N, z_shift))
+        return outs
