@@ -49,9 +49,10 @@ def parse_args():
                     help="log2 of the number of rows (default: 20; 24 for --workload ntt and 18 for --workload batch, the sizes "
                          "of the sharded-transform and batched-proof configurations)")
     ap.add_argument("--blowup", type=int, default=4, help="evaluation domain = blowup * n")
-    ap.add_argument("--workload", default="round23", choices=["round23", "ntt", "round23-sharded", "batch", "tables", "quotient", "msm"],
+    ap.add_argument("--workload", default="round23", choices=["round23", "ntt", "node-ntt", "round23-sharded", "batch", "tables", "quotient", "msm"],
                     help="round23: the headline metric (default). ntt: ONE four-step transform of 2^log-n points sharded over "
-                         "the GPUs (config 4 with --log-n 24). round23-sharded: ONE proof over all GPUs. "
+                         "the GPUs (config 4 with --log-n 24), one process per GPU over torch.distributed. node-ntt: the same transform "
+                         "through the library's native node layer (plk_node_ntt: ONE process, --gpus ranks, RCCL all-to-all). round23-sharded: ONE proof over all GPUs. "
                          "batch: --circuits independent circuits dealt round-robin (config 5 with --log-n 18 --circuits 64)")
     ap.add_argument("--circuits", type=int, default=64)
     ap.add_argument("--cpu-sample-log-n", type=int, default=20,
@@ -64,7 +65,7 @@ def parse_args():
                     help="skip the extra figure without the Int/Bool selector columns (a profiler run wants one launch shape per kernel)")
     args = ap.parse_args()
     if args.log_n is None:
-        args.log_n = {"ntt": 24, "batch": 18}.get(args.workload, 20)
+        args.log_n = {"ntt": 24, "node-ntt": 24, "batch": 18}.get(args.workload, 20)
     return args
 
 
@@ -362,6 +363,76 @@ def four_step_extra(prover, dist, world, device, log_N=24, steps=5, warmup=2):
             "transposed_output_ms": round(ms_t, 4), "round_trip_bit_exact": bool(int(ok.item())), "steps": steps, "scaling": "strong"}
 
 
+def node_ntt(args) -> int:
+    """--workload node-ntt: ONE transform of 2^log-n points over --gpus ranks held by THIS process (plk_node_ntt: a host
+    thread and a stream per rank, fused four-step phases, three all-to-all exchanges over RCCL; with
+    PLONK_BENCH_SHARE_GPU=1 the ranks share GPU 0 and exchange by device-to-device copies)."""
+    import torch
+    from plonk_amd.node import Node
+    G, N = args.gpus, 1 << args.log_n
+    share = os.environ.get("PLONK_BENCH_SHARE_GPU") == "1"
+    devices = [0] * G if share else list(range(G))
+    exchange = os.environ.get("PLONK_BENCH_NODE_EXCHANGE", "copy" if share else "rccl")
+    node = Node(devices, exchange=exchange)
+    m = N // G
+    xs = []
+    for g in range(G):
+        gen = torch.Generator(device=node.device(g))
+        gen.manual_seed(4321 + g)
+        x = torch.randint(-(1 << 63), (1 << 63) - 1, (m, 4), dtype=torch.int64, device=node.device(g), generator=gen)
+        x[:, 3] = x[:, 3] & ((1 << 62) - 1)          # canonical: below 2^254 < p
+        xs.append(x)
+    ys = node.ntt(xs, N)
+    back = node.ntt(ys, N, inverse=True)
+    node.sync()
+    ok = all(torch.equal(a, b) for a, b in zip(back, xs))
+    out = [torch.empty_like(x) for x in xs]
+
+    def timed_ms(natural):
+        for _ in range(args.warmup):
+            node.ntt(xs, N, natural_output=natural, out=out)
+        node.sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            node.ntt(xs, N, natural_output=natural, out=out)
+        node.sync()
+        return (time.perf_counter() - t0) * 1e3 / args.steps
+
+    ms, ms_t = timed_ms(True), timed_ms(False)
+    gelem = N / (ms * 1e-3) / 1e9
+    line = {"metric": f"four-step NTT of 2^{args.log_n} points, natural order in and out (native node layer)", "value": round(gelem, 3),
+            "unit": "Gelem/s", "n_gpus": G, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": f"one transform of N=2^{args.log_n} sharded contiguously over {G} rank(s) in one process "
+                                   f"(plk_node_ntt, exchange: {exchange}, devices {devices}), three all-to-all exchanges of "
+                                   f"{(G - 1) * N // (G * G) * 32 / 2**20:.1f} MiB per rank each"},
+            "frac_of_hbm_roofline": round(gelem / NTT_ROOFLINE_GELEM, 4), "transposed_output_ms": round(ms_t, 4),
+            "round_trip_bit_exact": bool(ok)}
+    node.close()
+    print(json.dumps(line), flush=True)
+    return 0 if ok else 6
+
+
+def node_ntt_extra(world: int, limit: int):
+    """Extra figure of a multi-GPU run, outside `value`: the sharded 2^24-point transform through the library's native
+    node layer (one process driving all the GPUs, RCCL bound by the library itself), run as a child process of rank 0
+    while the ranks of the main run wait.  Returns the child's line, or an object with an `error`."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK",
+                                                             "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "node-ntt", "--gpus", str(world), "--steps", "5", "--warmup", "2"]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=limit)
+    except subprocess.TimeoutExpired:
+        return {"error": f"did not finish within {limit} s"}
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": f"exit status {r.returncode}: " + (r.stderr.strip().splitlines() or ["no output"])[-1][:300]}
+    d = json.loads(lines[-1])
+    return {"what": d["config"]["workload"], "ms": d["ms_per_step"], "gelem_per_s": d["value"], "frac_of_hbm_roofline": d["frac_of_hbm_roofline"],
+            "transposed_output_ms": d["transposed_output_ms"], "round_trip_bit_exact": d["round_trip_bit_exact"]}
+
+
 def launch_ranks(args) -> int:
     """bench.py started alone with --gpus N > 1: start N ranks of this same command line through
     torch.distributed.run as a CHILD process (this process has not touched the GPU and never will), pass the child's
@@ -379,6 +450,8 @@ def launch_ranks(args) -> int:
 
 def main():
     args = parse_args()
+    if args.workload == "node-ntt":
+        sys.exit(node_ntt(args))              # one process holds every rank
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
     import torch
@@ -585,11 +658,20 @@ def main():
                 print(json.dumps(line), flush=True)
                 print("bench.py: the sharded transform's forward-then-inverse round trip did not return its input", file=sys.stderr, flush=True)
                 os._exit(6)
+    node_failed = False
+    if world > 1 and not args.no_four_step and rank == 0:
+        # the same transform once more through the native node layer (one child process over all the GPUs), while
+        # the other ranks wait at the barrier below
+        line["node_ntt"] = node_ntt_extra(world, args.four_step_limit)
+        node_failed = "error" in line["node_ntt"] or line["node_ntt"].get("round_trip_bit_exact") is False
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if node_failed:
+        print("bench.py: the native node layer's sharded transform failed: " + json.dumps(line["node_ntt"]), file=sys.stderr, flush=True)
+        sys.exit(7)
     if line is not None and line.get("matches_cpu") is False:
         print("bench.py: the GPU's outputs differ from the CPU restatement: " + json.dumps(line["matches_cpu_detail"]), file=sys.stderr, flush=True)
         sys.exit(4)

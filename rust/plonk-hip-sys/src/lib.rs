@@ -24,6 +24,27 @@ pub const PLK_ERR_NOMEM: c_int = -8;
 pub const PLK_NUM_WIRES: usize = 4;
 pub const PLK_NUM_SELECTORS: usize = 9;
 
+/// Opaque node (G ranks in one process), created by `plk_node_create`.
+#[repr(C)]
+pub struct plk_node {
+    _private: [u8; 0],
+}
+pub const PLK_NODE_RCCL: c_int = 0;
+pub const PLK_NODE_COPY: c_int = 1;
+
+/// `plk_circuit_io` of plonk_hip.h: one circuit of `plk_node_round23_batch` (device addresses).
+#[repr(C)]
+pub struct plk_circuit_io {
+    pub wires: [*const u64; 4],
+    pub sel: [*const u64; 9],
+    pub sigma: [*const u64; 4],
+    pub beta: [u64; 4],
+    pub gamma: [u64; 4],
+    pub z_out: *mut u64,
+    pub gate_out: *mut u64,
+    pub perm_out: *mut u64,
+}
+
 /// `plk_builder_fn`: fills up to `capacity` elements, returns how many evaluations the builder produced.
 pub type plk_builder_fn = unsafe extern "C" fn(user: *mut c_void, evals_out: *mut u64, capacity: usize) -> usize;
 
@@ -65,4 +86,34 @@ extern "C" {
     pub fn plk_round23(ctx: *mut plk_ctx, wires: *const *const u64, sel: *const *const u64, sigma: *const *const u64,
                        n: usize, big_n: usize, beta: *const u64, gamma: *const u64, z_shift: usize,
                        z_out: *mut u64, gate_out: *mut u64, perm_out: *mut u64) -> c_int;
+
+    // ---- device memory for a host without a HIP binding (no counterpart in the reference) ----
+    pub fn plk_dev_alloc(ctx: *mut plk_ctx, bytes: usize, out: *mut *mut c_void) -> c_int;
+    pub fn plk_dev_free(ctx: *mut plk_ctx, p: *mut c_void);
+    pub fn plk_dev_upload(ctx: *mut plk_ctx, stream: *mut c_void, dst_dev: *mut c_void, src_host: *const c_void, bytes: usize) -> c_int;
+    pub fn plk_dev_download(ctx: *mut plk_ctx, stream: *mut c_void, dst_host: *mut c_void, src_dev: *const c_void, bytes: usize) -> c_int;
+    pub fn plk_ctx_stream(ctx: *mut plk_ctx) -> *mut c_void;
+    /// rounds 2+3 on columns resident on the context's GPU, enqueued on `stream`
+    pub fn plk_dev_round23(ctx: *mut plk_ctx, stream: *mut c_void, wires: *const *const u64, sel: *const *const u64,
+                           sigma: *const *const u64, n: usize, big_n: usize, beta: *const u64, gamma: *const u64, z_shift: usize,
+                           z_out: *mut u64, gate_out: *mut u64, perm_out: *mut u64) -> c_int;
+    pub fn plk_dev_status(ctx: *mut plk_ctx, stream: *mut c_void) -> c_int;
+
+    // ---- one node: G ranks in one process, one GPU each (no counterpart in the reference) ----
+    /// `exchange`: PLK_NODE_RCCL (one GPU per rank) or PLK_NODE_COPY (device-to-device copies; ranks may share a GPU)
+    pub fn plk_node_create(devices: *const c_int, ranks: usize, exchange: c_int, out: *mut *mut plk_node) -> c_int;
+    pub fn plk_node_destroy(node: *mut plk_node);
+    pub fn plk_node_ranks(node: *const plk_node) -> usize;
+    pub fn plk_node_ctx(node: *mut plk_node, rank: usize) -> *mut plk_ctx;
+    pub fn plk_node_last_error(node: *const plk_node) -> *const c_char;
+    /// one transform of `big_n` points over the node's ranks (four-step form, three all-to-all exchanges);
+    /// in_shards[g] / out_shards[g]: big_n / ranks elements on rank g's GPU
+    pub fn plk_node_ntt(node: *mut plk_node, in_shards: *const *const u64, big_n: usize, inverse: c_int, natural_output: c_int,
+                        out_shards: *const *mut u64) -> c_int;
+    /// the same on host arrays: src/polynomial_utils.rs:29 / src/execution_trace.rs:362-370 at sizes sharded over the node
+    pub fn plk_node_ntt_host(node: *mut plk_node, input: *const u64, big_n: usize, inverse: c_int, out: *mut u64) -> c_int;
+    pub fn plk_node_sync(node: *mut plk_node) -> c_int;
+    /// batched proofs: circuit i on rank i % ranks, all its pointers in that rank's GPU memory
+    pub fn plk_node_round23_batch(node: *mut plk_node, circuits: *const plk_circuit_io, count: usize, n: usize, big_n: usize,
+                                  z_shift: usize) -> c_int;
 }

@@ -198,6 +198,63 @@ fn padded<F: Field>(p: &DensePolynomial<F>, len: usize) -> Vec<F> {
     v
 }
 
+// ------------------------------------------------------------------------------------------- the node (several GPUs)
+
+struct Node(*mut sys::plk_node);
+unsafe impl Send for Node {}
+
+/// `PLONK_HIP_NODE_DEVICES=0,1,2,3,4,5,6,7` makes transforms of at least `PLONK_HIP_NODE_MIN_SIZE` points (default
+/// 2^22) run sharded over those GPUs (four-step form, RCCL all-to-all; `PLONK_HIP_NODE_EXCHANGE=copy` selects
+/// device-to-device copies instead).  Created at the first such call; `None` when the variable is not set.
+static NODE: Mutex<Option<Option<Node>>> = Mutex::new(None);
+
+fn node_min_size() -> usize {
+    std::env::var("PLONK_HIP_NODE_MIN_SIZE").ok().and_then(|s| s.parse().ok()).unwrap_or(1 << 22)
+}
+
+/// Runs `f` on the node if one is configured and returns true; false = no node, the caller takes the one-GPU path.
+/// As in `with_ctx`, a failure is carried out of the locked region as text and raised after the guard is gone.
+fn with_node(f: impl FnOnce(*mut sys::plk_node) -> Result<(), String>) -> bool {
+    let outcome: Option<Result<(), String>> = {
+        let mut guard = NODE.lock().unwrap_or_else(|e| e.into_inner());
+        let mut create_failure: Option<String> = None;
+        if guard.is_none() {
+            let devices: Vec<i32> = std::env::var("PLONK_HIP_NODE_DEVICES")
+                .map(|s| s.split(',').filter_map(|d| d.trim().parse().ok()).collect())
+                .unwrap_or_default();
+            if devices.is_empty() {
+                *guard = Some(None);
+            } else {
+                let exchange = match std::env::var("PLONK_HIP_NODE_EXCHANGE").as_deref() {
+                    Ok("copy") => sys::PLK_NODE_COPY,
+                    _ => sys::PLK_NODE_RCCL,
+                };
+                let mut p: *mut sys::plk_node = ptr::null_mut();
+                let rc = unsafe { sys::plk_node_create(devices.as_ptr(), devices.len(), exchange, &mut p) };
+                if rc == sys::PLK_OK {
+                    *guard = Some(Some(Node(p)));
+                } else {
+                    *guard = Some(None); // later calls take the one-GPU path
+                    create_failure = Some(format!("plk_node_create({:?}) failed: {}", devices, strerror(rc)));
+                }
+            }
+        }
+        if let Some(msg) = create_failure {
+            Some(Err(msg))
+        } else {
+            match guard.as_ref().unwrap() {
+                Some(node) => Some(f(node.0)),
+                None => None,
+            }
+        }
+    }; // the guard is gone here
+    match outcome {
+        Some(Err(msg)) => panic!("{}", msg),
+        Some(Ok(())) => true,
+        None => false,
+    }
+}
+
 // ------------------------------------------------------------------------------------------- src/polynomial_utils.rs
 
 /// src/polynomial_utils.rs:18-33.
@@ -205,6 +262,19 @@ pub fn evaluations_to_dense_polynomial<F: FftField>(evals: &[F], domain: &Genera
     check_field::<F>();
     assert_eq!(evals.len(), domain.size(), "Evaluation length must match the domain size");
     let mut coeffs = vec![F::zero(); domain.size()];
+    // a large transform on a configured node: sharded over its GPUs
+    if domain.size() >= node_min_size()
+        && with_node(|node| {
+            let rc = unsafe { sys::plk_node_ntt_host(node, limbs(evals), evals.len(), 1, limbs_mut(&mut coeffs)) };
+            if rc == sys::PLK_OK {
+                Ok(())
+            } else {
+                Err(format!("libplonk_hip: {}", unsafe { CStr::from_ptr(sys::plk_node_last_error(node)) }.to_string_lossy()))
+            }
+        })
+    {
+        return DensePolynomial::from_coefficients_vec(coeffs);
+    }
     with_ctx(|ctx| {
         let rc = unsafe { sys::plk_intt(ctx, limbs(evals), evals.len(), domain.size(), limbs_mut(&mut coeffs)) };
         check(ctx, rc, "Evaluation length must match the domain size")

@@ -148,3 +148,5 @@ def test_bench_starts_its_own_ranks():
     line = lines[0]
     assert line["n_gpus"] == 2 and line["config"]["circuits_per_step"] == 2
     assert line["four_step"]["round_trip_bit_exact"] is True and line["four_step"]["ms"] > 0
+    # and the same transform through the native node layer (a child process of rank 0: two ranks, copy exchange here)
+    assert line["node_ntt"]["round_trip_bit_exact"] is True and line["node_ntt"]["ms"] > 0
