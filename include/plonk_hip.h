@@ -5,9 +5,9 @@
  * a Rust caller binds these symbols from an `extern "C"` block and keeps its signatures.
  *
  * Conventions
- *  - Field: BLS12-381 scalar field.  An element is 4 little-endian uint64_t limbs in Montgomery
- *    form with R = 2^256 — byte-for-byte the memory of ark-ff 0.3 `Fp256<P>` (`x.0.0`).
- *    Columns are contiguous arrays of elements (n * 4 uint64_t).
+ *  - Field: the field of the context (BLS12-381 scalar field unless created otherwise, see "fields").  An element is
+ *    4 little-endian uint64_t limbs in Montgomery form with R = 2^256 — byte-for-byte the memory of ark-ff 0.3
+ *    `Fp256<P>` (`x.0.0`).  Columns are contiguous arrays of elements (n * 4 uint64_t).
  *  - sigma columns are arrays of uint64_t row indices (`PermutationTable<usize>`,
  *    src/permutation_polynomial.rs:51-61).
  *  - `sel[k]` / `sel_out[k]` are indexed by `ASTKind` declaration order
@@ -58,7 +58,7 @@ enum {
   PLK_OK = 0,
   PLK_ERR_LENGTH = -1,           /* assert_eq!(evals.len(), domain.size()) — src/polynomial_utils.rs:22-26, :56-60 */
   PLK_ERR_NOT_POW2 = -2,         /* domain size is not a power of two (Radix2EvaluationDomain only) */
-  PLK_ERR_TWO_ADICITY = -3,      /* log2(domain size) exceeds the field's two-adicity (32) */
+  PLK_ERR_TWO_ADICITY = -3,      /* log2(domain size) exceeds the field's two-adicity (32 for BLS12-381 Fr) */
   PLK_ERR_ZERO_DENOMINATOR = -4, /* `denominator.inverse().unwrap()` — src/permutation_polynomial.rs:258 */
   PLK_ERR_SIGMA_RANGE = -5,      /* slice index out of bounds — src/permutation_polynomial.rs:235-238 */
   PLK_ERR_HIP = -6,              /* HIP runtime failure (see plk_last_error) */
@@ -72,8 +72,31 @@ enum {
 #define PLK_INPUT_FIELD 0u  /* column of field elements */
 #define PLK_INPUT_U64 1u    /* column of uint64_t indices, converted with F::from(u64) on load */
 
+/* ---- fields ------------------------------------------------------------------------------ */
+
+/* The reference's functions are generic over `F: FftField`; the one field it names, `ark_tweedle::Fr`
+ * (src/main.rs:3), comes from a crate its manifest does not list.  The library is instantiated for:
+ *   PLK_FIELD_BLS12_381_FR  the BLS12-381 scalar field (two-adicity 32, generator 7) - the default, the field every
+ *                           figure and every parity statement of this library is made for; its root of unity is
+ *                           the constant arkworks publishes;
+ *   PLK_FIELD_TWEEDLE_FR    the scalar field of Tweedledee, 2^254 + 4707489544292117082687961190295928833
+ *                           (two-adicity 34).  Its generator (5) and root of unity are SELF-DERIVED
+ *                           (tools/derive_field_constants.py): no arkworks source was available to compare with, so
+ *                           transforms agree with ark-poly only if ark-ff's Tweedle parameters use the same generator.
+ * A context is created for one field; every call on it computes in that field.  The commitment entry points
+ * (plk_msm_*, plk_dev_msm_*, plk_dev_g1_multiples) exist for BLS12-381 only and return PLK_ERR_ARG otherwise. */
+enum { PLK_FIELD_BLS12_381_FR = 0, PLK_FIELD_TWEEDLE_FR = 1, PLK_NUM_FIELDS = 2 };
+
 /* ---- context ---------------------------------------------------------------------------- */
 
+/* plk_ctx_create = plk_ctx_create_field with PLK_FIELD_BLS12_381_FR */
+int plk_ctx_create_field(int device, int field_id, plk_ctx** out);
+/* the field a context was created for; its name ("BLS12-381 Fr", "Tweedle Fr"; NULL for an unknown id) */
+int plk_ctx_field(const plk_ctx* ctx);
+const char* plk_field_name(int field_id);
+/* plk_field_constants for any field: modulus, R mod p, R^2 mod p (R = 2^256), any pointer may be NULL;
+ * returns PLK_ERR_ARG for an unknown id */
+int plk_field_constants_of(int field_id, uint64_t modulus[4], uint64_t one[4], uint64_t r2[4]);
 int plk_ctx_create(int device, plk_ctx** out);
 void plk_ctx_destroy(plk_ctx* ctx);
 const char* plk_strerror(int code);
@@ -414,8 +437,10 @@ void* plk_ctx_stream(plk_ctx* ctx);
 typedef struct plk_node plk_node;
 enum { PLK_NODE_RCCL = 0, PLK_NODE_COPY = 1 };
 
-/* devices[g] = GPU of rank g (G a power of two, 1 <= G <= 64).  PLK_NODE_RCCL needs G different devices. */
+/* devices[g] = GPU of rank g (G a power of two, 1 <= G <= 64).  PLK_NODE_RCCL needs G different devices.
+ * plk_node_create = plk_node_create_field with PLK_FIELD_BLS12_381_FR. */
 int plk_node_create(const int* devices, size_t G, int exchange, plk_node** out);
+int plk_node_create_field(const int* devices, size_t G, int exchange, int field_id, plk_node** out);
 void plk_node_destroy(plk_node* node);
 size_t plk_node_ranks(const plk_node* node);
 /* rank g's context (owned by the node): for plk_dev_alloc / plk_dev_upload / plk_dev_* calls on that rank's GPU */

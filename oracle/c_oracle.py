@@ -26,21 +26,44 @@ class OracleError(RuntimeError):
         self.code, self.row = code, row
 
 
+#: the same restatement compiled over the second field (ORACLE_FIELD=1: Tweedle Fr)
+LIB_PATHS = {0: LIB_PATH, 1: os.path.join(_HERE, "liboracle_tweedle.so")}
+
+
 def build():
-    subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+    subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so", "liboracle_tweedle.so"])
 
 
-_lib = None
+_libs = {}
+_field = 0
 
 
 def lib():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
+    if _field not in _libs:
+        if not os.path.exists(LIB_PATHS[_field]):
             build()
-        _lib = C.CDLL(LIB_PATH)
-        _lib.orc_fe_inverse.restype = C.c_int
-    return _lib
+        l = C.CDLL(LIB_PATHS[_field])
+        l.orc_fe_inverse.restype = C.c_int
+        _libs[_field] = l
+    return _libs[_field]
+
+
+class use_field:
+    """`with use_field(1): ...` routes every call of this module to the library built for that field (the
+    G1 functions exist for field 0 only)."""
+
+    def __init__(self, field_id: int):
+        self.id = field_id
+
+    def __enter__(self):
+        global _field
+        self.prev, _field = _field, self.id
+        return self
+
+    def __exit__(self, *exc):
+        global _field
+        _field = self.prev
+        return False
 
 
 def _p(a):

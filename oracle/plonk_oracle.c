@@ -29,6 +29,13 @@ typedef unsigned __int128 u128;
 typedef uint64_t u64;
 typedef struct { u64 l[4]; } fe;
 
+/* The field: ORACLE_FIELD = 0 (default) the BLS12-381 scalar field, 1 the scalar field of Tweedledee
+ * (2^254 + 4707489544292117082687961190295928833; liboracle_tweedle.so).  Constants as printed by
+ * tools/derive_field_constants.py; the Tweedle generator (5) and root are self-derived, see there. */
+#ifndef ORACLE_FIELD
+#define ORACLE_FIELD 0
+#endif
+#if ORACLE_FIELD == 0
 static const fe MODULUS = {{0xffffffff00000001ull, 0x53bda402fffe5bfeull, 0x3339d80809a1d805ull, 0x73eda753299d7d48ull}};
 static const fe R_ONE   = {{0x00000001fffffffeull, 0x5884b7fa00034802ull, 0x998c4fefecbc4ff5ull, 0x1824b159acc5056full}};
 static const fe R2      = {{0xc999e990f3f29c6dull, 0x2b6cedcb87925c23ull, 0x05d314967254398full, 0x0748d9d99f59ff11ull}};
@@ -36,6 +43,17 @@ static const fe R2      = {{0xc999e990f3f29c6dull, 0x2b6cedcb87925c23ull, 0x05d3
 static const fe ROOT_CANON = {{0x3829971f439f0d2bull, 0xb63683508c2280b9ull, 0xd09b681922c813b4ull, 0x16a2a19edfe81f20ull}};
 #define INV64 0xfffffffeffffffffull /* -p^-1 mod 2^64 */
 #define TWO_ADICITY 32
+#elif ORACLE_FIELD == 1
+static const fe MODULUS = {{0x842cafd400000001ull, 0x038aa127696286c9ull, 0x0000000000000000ull, 0x4000000000000000ull}};
+static const fe R_ONE   = {{0x7379f083fffffffdull, 0xf5601c89c3d86ba3ull, 0xffffffffffffffffull, 0x3fffffffffffffffull}};
+static const fe R2      = {{0x8595fa8000000010ull, 0x7e16a565c6895230ull, 0xf4c0e6fcb03aa0a2ull, 0x00c8ad9106886013ull}};
+/* GENERATOR^((p-1)/2^34) with GENERATOR = 5 (self-derived), canonical form */
+static const fe ROOT_CANON = {{0x1cbd3234869d57ecull, 0x0a287dd1b8084fbfull, 0xf1dbcb645a987293ull, 0x113efc510dc03c0bull}};
+#define INV64 0x842cafd3ffffffffull
+#define TWO_ADICITY 34
+#else
+#error "unknown ORACLE_FIELD"
+#endif
 
 enum { ORC_OK = 0, ORC_ERR_LENGTH = -1, ORC_ERR_NOT_POW2 = -2, ORC_ERR_TWO_ADICITY = -3,
        ORC_ERR_ZERO_DENOMINATOR = -4, ORC_ERR_SIGMA_RANGE = -5, ORC_ERR_NOMEM = -8 };

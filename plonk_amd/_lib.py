@@ -37,6 +37,10 @@ u32p = C.POINTER(C.c_uint32)
 u8p = C.POINTER(C.c_uint8)
 BUILDER_FN = C.CFUNCTYPE(C.c_size_t, C.c_void_p, u64p, C.c_size_t)
 
+FIELD_BLS12_381_FR = 0
+FIELD_TWEEDLE_FR = 1
+FIELD_IDS = {"bls12_381_fr": FIELD_BLS12_381_FR, "tweedle_fr": FIELD_TWEEDLE_FR}
+
 NODE_RCCL = 0
 NODE_COPY = 1
 
@@ -51,6 +55,10 @@ class CircuitIO(C.Structure):
 #: every symbol include/plonk_hip.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "plk_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "plk_ctx_create_field": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "plk_ctx_field": (C.c_int, [C.c_void_p]),
+    "plk_field_name": (C.c_char_p, [C.c_int]),
+    "plk_field_constants_of": (C.c_int, [C.c_int, u64p, u64p, u64p]),
     "plk_ctx_destroy": (None, [C.c_void_p]),
     "plk_strerror": (C.c_char_p, [C.c_int]),
     "plk_last_error": (C.c_char_p, [C.c_void_p]),
@@ -110,6 +118,7 @@ SIGNATURES = {
     "plk_dev_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "plk_ctx_stream": (C.c_void_p, [C.c_void_p]),
     "plk_node_create": (C.c_int, [C.POINTER(C.c_int), C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]),
+    "plk_node_create_field": (C.c_int, [C.POINTER(C.c_int), C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "plk_node_destroy": (None, [C.c_void_p]),
     "plk_node_ranks": (C.c_size_t, [C.c_void_p]),
     "plk_node_ctx": (C.c_void_p, [C.c_void_p, C.c_size_t]),

@@ -158,15 +158,17 @@ def _fe(x) -> np.ndarray:
 
 
 class Context:
-    """One library context (one GPU).  `default()` creates it on first use on device 0."""
+    """One library context (one GPU, one field).  `default()` creates it on first use on device 0 for the BLS12-381
+    scalar field; `field` is a PLK_FIELD_* number or one of `_lib.FIELD_IDS`' names."""
     _default: Optional["Context"] = None
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, field=0):
         self.lib = _lib.load()
+        self.field = _lib.FIELD_IDS[field] if isinstance(field, str) else int(field)
         h = C.c_void_p()
-        rc = self.lib.plk_ctx_create(device, C.byref(h))
+        rc = self.lib.plk_ctx_create_field(device, self.field, C.byref(h))
         if rc != _lib.PLK_OK:
-            raise PlonkError(rc, f"plk_ctx_create(device={device}): {self.lib.plk_strerror(rc).decode()}")
+            raise PlonkError(rc, f"plk_ctx_create_field(device={device}, field={field}): {self.lib.plk_strerror(rc).decode()}")
         self.handle = h
         self.device = device
 
@@ -340,13 +342,15 @@ def build_permutation_constraint_evaluation_polynomial(polynomials: PermutationP
 
 
 #: F::multiplicative_generator() of BLS12-381 Fr: the coset shift ark-poly 0.3's coset_fft uses
-MULTIPLICATIVE_GENERATOR = 7
+#: `F::multiplicative_generator()` per field id (7 is ark-ff's for BLS12-381 Fr; 5 for the Tweedle field is self-derived)
+MULTIPLICATIVE_GENERATORS = {0: 7, 1: 5}
+MULTIPLICATIVE_GENERATOR = MULTIPLICATIVE_GENERATORS[0]
 
 
-def _shift(shift) -> np.ndarray:
+def _shift(shift, ctx: "Context") -> np.ndarray:
     if shift is None:
-        from .synth import ints_to_mont
-        return _fe(ints_to_mont([MULTIPLICATIVE_GENERATOR])[0])
+        from .synth import field
+        return _fe(field(ctx.field).ints_to_mont([MULTIPLICATIVE_GENERATORS[ctx.field]])[0])
     return _fe(shift)
 
 
@@ -355,7 +359,7 @@ def coset_fft(coeffs: np.ndarray, domain: Radix2EvaluationDomain, shift=None, ct
     c = _ctx(ctx)
     coeffs = _col(coeffs, "coeffs")
     out = np.empty((domain.size(), 4), dtype=np.uint64)
-    c.check(c.lib.plk_coset_ntt(c.handle, _p(coeffs), coeffs.shape[0], domain.size(), _p(_shift(shift)), 0, _p(out)))
+    c.check(c.lib.plk_coset_ntt(c.handle, _p(coeffs), coeffs.shape[0], domain.size(), _p(_shift(shift, c)), 0, _p(out)))
     return out
 
 
@@ -364,7 +368,7 @@ def coset_ifft(evals: np.ndarray, domain: Radix2EvaluationDomain, shift=None, ct
     c = _ctx(ctx)
     evals = _col(evals, "evals")
     out = np.empty((domain.size(), 4), dtype=np.uint64)
-    c.check(c.lib.plk_coset_ntt(c.handle, _p(evals), evals.shape[0], domain.size(), _p(_shift(shift)), 1, _p(out)))
+    c.check(c.lib.plk_coset_ntt(c.handle, _p(evals), evals.shape[0], domain.size(), _p(_shift(shift, c)), 1, _p(out)))
     return out
 
 
@@ -378,7 +382,7 @@ def quotient_polynomial(numerators: Sequence[np.ndarray], alpha: np.ndarray, n_d
     if any(a.shape[0] != N for a in nums):
         raise LengthMismatch(_lib.PLK_ERR_LENGTH, "Evaluation length must match the domain size")
     out = np.empty((N, 4), dtype=np.uint64)
-    c.check(c.lib.plk_quotient(c.handle, _table(nums), len(nums), _p(_fe(alpha)), n_domain.size(), N, _p(_shift(shift)), _p(out)))
+    c.check(c.lib.plk_quotient(c.handle, _table(nums), len(nums), _p(_fe(alpha)), n_domain.size(), N, _p(_shift(shift, c)), _p(out)))
     return out
 
 

@@ -1,6 +1,12 @@
 // C ABI of the library (declared in include/plonk_hip.h): context, transform plans,
 // workspace, and the host- and device-pointer entry points built on the kernels in
 // ntt.cuh, grand_product.cuh and constraints.cuh.
+//
+// This file is ONE FIELD's instantiation of the library: it is compiled once per field (-DPLK_FIELD_ID=0, 1, ...;
+// field.cuh holds the table), field_syms.h renames its entry points to plkf<ID>_... and its namespace to
+// plk_field<ID>, and dispatch.cpp defines the public names, forwarding by the field of the context.
+#include "field_syms.h"
+
 #include "../../include/plonk_hip.h"
 
 #include <hip/hip_runtime.h>
@@ -141,6 +147,7 @@ struct CopyPool {
 };
 
 struct plk_ctx {
+  int field_id = PLK_FIELD_ID;   // FIRST member: dispatch.cpp reads it to pick the instantiation
   int device = 0;
   CopyLane copy_lanes[COPY_WORKERS];
   CopyPool copy_pool;
@@ -2081,6 +2088,7 @@ int plk_dev_grand_product_finish(plk_ctx* ctx, void* stream, size_t rows, const 
 
 int plk_dev_msm_set_bases(plk_ctx* ctx, const uint64_t* bases_dev, size_t n) {
   HOST_CALL(ctx);
+  if (!Field::HAS_G1) return fail(ctx, PLK_ERR_ARG, std::string("commitments are sums in BLS12-381 G1: not available for ") + Field::NAME);
   if (!bases_dev && n) return fail(ctx, PLK_ERR_ARG, "null pointer");
   HIP_TRY(ctx, hipDeviceSynchronize());          // the caller's table may have been written on any stream
   return msm_build_table(ctx, ctx->stream, bases_dev, n);
@@ -2088,6 +2096,7 @@ int plk_dev_msm_set_bases(plk_ctx* ctx, const uint64_t* bases_dev, size_t n) {
 
 int plk_dev_msm_g1(plk_ctx* ctx, void* stream, const uint64_t* scalars_dev, size_t n, uint64_t out_xy[12]) {
   STREAM_CALL(ctx, stream);
+  if (!Field::HAS_G1) return fail(ctx, PLK_ERR_ARG, std::string("commitments are sums in BLS12-381 G1: not available for ") + Field::NAME);
   if (!scalars_dev && n) return fail(ctx, PLK_ERR_ARG, "null pointer");
   const uint64_t* one[1] = {scalars_dev};
   return launch_msm(ctx, (hipStream_t)stream, one, 1, n, out_xy);
@@ -2095,11 +2104,13 @@ int plk_dev_msm_g1(plk_ctx* ctx, void* stream, const uint64_t* scalars_dev, size
 
 int plk_dev_msm_g1_batch(plk_ctx* ctx, void* stream, const uint64_t* const scalars_dev[], size_t count, size_t n, uint64_t* out_xy) {
   STREAM_CALL(ctx, stream);
+  if (!Field::HAS_G1) return fail(ctx, PLK_ERR_ARG, std::string("commitments are sums in BLS12-381 G1: not available for ") + Field::NAME);
   return launch_msm(ctx, (hipStream_t)stream, scalars_dev, count, n, out_xy);
 }
 
 int plk_dev_g1_multiples(plk_ctx* ctx, void* stream, const uint64_t base_xy[12], uint64_t first, size_t count, uint64_t* out_dev) {
   STREAM_CALL(ctx, stream);
+  if (!Field::HAS_G1) return fail(ctx, PLK_ERR_ARG, std::string("commitments are sums in BLS12-381 G1: not available for ") + Field::NAME);
   if (!base_xy || (!out_dev && count)) return fail(ctx, PLK_ERR_ARG, "null pointer");
   if (count == 0) return PLK_OK;
   G1Affine b;
@@ -2404,6 +2415,7 @@ int plk_grand_product(plk_ctx* ctx, const uint64_t* const wires[4], const uint64
 int plk_msm_set_bases(plk_ctx* ctx, const uint64_t* bases_host, size_t n) {
   HOST_CALL(ctx);
   int rc;
+  if (!Field::HAS_G1) return fail(ctx, PLK_ERR_ARG, std::string("commitments are sums in BLS12-381 G1: not available for ") + Field::NAME);
   if (!bases_host && n) return fail(ctx, PLK_ERR_ARG, "null pointer");
   if (n == 0) { msm_free_table(ctx); return PLK_OK; }
   uint64_t* d = nullptr;
@@ -2418,6 +2430,7 @@ int plk_msm_set_bases(plk_ctx* ctx, const uint64_t* bases_host, size_t n) {
 int plk_msm_g1(plk_ctx* ctx, const uint64_t* scalars_host, size_t n, uint64_t out_xy[12]) {
   HOST_CALL(ctx);
   int rc;
+  if (!Field::HAS_G1) return fail(ctx, PLK_ERR_ARG, std::string("commitments are sums in BLS12-381 G1: not available for ") + Field::NAME);
   if (!scalars_host && n) return fail(ctx, PLK_ERR_ARG, "null pointer");
   Staged st(ctx);
   void* d;
@@ -2448,6 +2461,7 @@ int plk_g1_sum(const uint64_t* points_xy, size_t count, uint64_t out_xy[12]) {
 int plk_msm_g1_batch(plk_ctx* ctx, const uint64_t* const scalars_host[], size_t count, size_t n, uint64_t* out_xy) {
   HOST_CALL(ctx);
   int rc;
+  if (!Field::HAS_G1) return fail(ctx, PLK_ERR_ARG, std::string("commitments are sums in BLS12-381 G1: not available for ") + Field::NAME);
   if (!scalars_host && count) return fail(ctx, PLK_ERR_ARG, "null pointer");
   Staged st(ctx);
   std::vector<const uint64_t*> d(count);

@@ -16,8 +16,16 @@ namespace plk {
 
 struct Fe { uint32_t l[8]; };
 
-// BLS12-381 scalar field.  Constants are re-derived in tests/test_constants.py.
+// The fields the library is instantiated for.  Every constant below is printed by tools/derive_field_constants.py
+// from the modulus alone (and re-derived by the tests); the transform arithmetic of fr29.cuh needs p < 2^255 and
+// p = 1 mod 2^29.  QEST = (2^232 / p) (1 - 2^-20) rounded down to a float (fr29.cuh, fe_reduce_f9).
+
+// BLS12-381 scalar field (field 0, the default).  Generator 7 and the root below are the constants arkworks
+// publishes for this field.
 struct Bls12_381Fr {
+  static constexpr int ID = 0;
+  static constexpr const char* NAME = "BLS12-381 Fr";
+  static constexpr bool HAS_G1 = true;     // the commitments (g1.cuh, msm.cuh) are sums in this field's curve
   static constexpr uint32_t P[8]  = {0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u,
                                      0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u};
   // R mod p (the field's one)
@@ -31,9 +39,43 @@ struct Bls12_381Fr {
   // GENERATOR^((p-1)/2^32), GENERATOR = 7, canonical (non-Montgomery) limbs
   static constexpr uint32_t ROOT[8] = {0x439f0d2bu, 0x3829971fu, 0x8c2280b9u, 0xb6368350u,
                                        0x22c813b4u, 0xd09b6819u, 0xdfe81f20u, 0x16a2a19eu};
+  static constexpr float QEST = 0x1.1aa838p-23f;
 };
 
+// Scalar field of Tweedledee, 2^254 + 4707489544292117082687961190295928833 (field 1): the reference names
+// `ark_tweedle::Fr` (src/main.rs:3), a crate its manifest does not list.  Generator 5 (the smallest quadratic
+// non-residue) and the root derived from it are SELF-DERIVED: no arkworks source is available to check them
+// against, so parity with ark-ff's constants for this field is unverifiable.
+struct TweedleFr {
+  static constexpr int ID = 1;
+  static constexpr const char* NAME = "Tweedle Fr";
+  static constexpr bool HAS_G1 = false;
+  static constexpr uint32_t P[8]  = {0x00000001u, 0x842cafd4u, 0x696286c9u, 0x038aa127u,
+                                     0x00000000u, 0x00000000u, 0x00000000u, 0x40000000u};
+  static constexpr uint32_t ONE[8] = {0xfffffffdu, 0x7379f083u, 0xc3d86ba3u, 0xf5601c89u,
+                                      0xffffffffu, 0xffffffffu, 0xffffffffu, 0x3fffffffu};
+  static constexpr uint32_t R2[8] = {0x00000010u, 0x8595fa80u, 0xc6895230u, 0x7e16a565u,
+                                     0xb03aa0a2u, 0xf4c0e6fcu, 0x06886013u, 0x00c8ad91u};
+  static constexpr uint32_t INV32 = 0xffffffffu;
+  static constexpr int TWO_ADICITY = 34;
+  // 5^((p-1)/2^34)
+  static constexpr uint32_t ROOT[8] = {0x869d57ecu, 0x1cbd3234u, 0xb8084fbfu, 0x0a287dd1u,
+                                       0x5a987293u, 0xf1dbcb64u, 0x0dc03c0bu, 0x113efc51u};
+  static constexpr float QEST = 0x1.ffffdep-23f;
+};
+
+// One translation unit = one field: PLK_FIELD_ID picks it (capi.hip is compiled once per field).
+#ifndef PLK_FIELD_ID
+#define PLK_FIELD_ID 0
+#endif
+#if PLK_FIELD_ID == 0
 using Field = Bls12_381Fr;
+#elif PLK_FIELD_ID == 1
+using Field = TweedleFr;
+#else
+#error "unknown PLK_FIELD_ID"
+#endif
+static_assert(Field::ID == PLK_FIELD_ID, "field table out of order");
 
 __host__ __device__ __forceinline__ Fe fe_zero() { Fe r; for (int i = 0; i < 8; ++i) r.l[i] = 0; return r; }
 __host__ __device__ __forceinline__ Fe fe_one() { Fe r; for (int i = 0; i < 8; ++i) r.l[i] = Field::ONE[i]; return r; }
@@ -515,6 +557,14 @@ __device__ __forceinline__ void fe_store(uint64_t* base, size_t idx, const Fe& v
   uint4* p = reinterpret_cast<uint4*>(base) + 2 * idx;
   p[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
   p[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+// the same store marked non-temporal: the line is not kept in the caches it passes through
+__device__ __forceinline__ void fe_store_nt(uint64_t* base, size_t idx, const Fe& v) {
+  typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+  v4u* p = reinterpret_cast<v4u*>(base) + 2 * idx;
+  const v4u lo = {v.l[0], v.l[1], v.l[2], v.l[3]}, hi = {v.l[4], v.l[5], v.l[6], v.l[7]};
+  __builtin_nontemporal_store(lo, p);
+  __builtin_nontemporal_store(hi, p + 1);
 }
 
 }  // namespace plk

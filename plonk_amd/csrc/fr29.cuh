@@ -127,7 +127,7 @@ __host__ __device__ __forceinline__ Fe fe_reduce_f9_by_subtractions(F9 a) {
 // conditional subtraction, instead of five conditional subtractions.
 __host__ __device__ __forceinline__ Fe fe_reduce_f9(F9 a) {
   f9_normalize(a);
-  const uint32_t qh = (uint32_t)((float)a.l[8] * 0x1.1aa838p-23f);
+  const uint32_t qh = (uint32_t)((float)a.l[8] * Field::QEST);
   int64_t acc = 0;
   F9 r;
 #pragma unroll

@@ -309,8 +309,13 @@ int ntt_check(plk_node* node, size_t N, size_t* N1, size_t* N2) {
 extern "C" {
 
 int plk_node_create(const int* devices, size_t G, int exchange, plk_node** out) {
+  return plk_node_create_field(devices, G, exchange, PLK_FIELD_BLS12_381_FR, out);
+}
+
+int plk_node_create_field(const int* devices, size_t G, int exchange, int field_id, plk_node** out) {
   if (!out) return PLK_ERR_ARG;
   *out = nullptr;
+  if (field_id < 0 || field_id >= PLK_NUM_FIELDS) return PLK_ERR_ARG;
   if (!devices || G == 0 || G > 64 || (G & (G - 1)) || (exchange != PLK_NODE_RCCL && exchange != PLK_NODE_COPY)) return PLK_ERR_ARG;
   if (exchange == PLK_NODE_RCCL)
     for (size_t a = 0; a < G; ++a)
@@ -328,7 +333,7 @@ int plk_node_create(const int* devices, size_t G, int exchange, plk_node** out) 
   for (size_t g = 0; g < G && rc == PLK_OK; ++g) {
     Rank& me = node->r[g];
     me.device = devices[g];
-    rc = plk_ctx_create(me.device, &me.ctx);
+    rc = plk_ctx_create_field(me.device, field_id, &me.ctx);
     if (rc) break;
     me.stream = (hipStream_t)plk_ctx_stream(me.ctx);
     hipError_t e = hipSetDevice(me.device);

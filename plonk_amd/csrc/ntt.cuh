@@ -25,6 +25,9 @@
 
 namespace plk {
 
+#ifndef PLK_NT_PASS_STORE
+#define PLK_NT_PASS_STORE 0      // measurement knob: non-temporal stores of a non-final pass's outputs
+#endif
 constexpr int TW_WORDS = 12;                // one twiddle record (9 limbs + padding)
 constexpr int NTT_TILE_LOG = 11;            // elements per workgroup tile
 constexpr int NTT_TILE = 1 << NTT_TILE_LOG;
@@ -390,7 +393,11 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void ntt_pass_kernel(const NttPassA
         const uint64_t q = q0 + c;
         const F9 tw = full ? f9_load_tw(full, ((uint64_t)k << log_inner) + q)
                            : twiddle_two_level(hi, a.tab.tw_lo, a.tab.lo_bits, ((uint64_t)k * q) << shift);
+#if PLK_NT_PASS_STORE
+        fe_store_nt(out, base + ((uint64_t)k << log_inner) + c, fe_pack_f9(mont29(v, tw)));
+#else
         fe_store(out, base + ((uint64_t)k << log_inner) + c, fe_pack_f9(mont29(v, tw)));
+#endif
       };
   tile_transform_any<BIG, LR>(tile, log_r, log_c, a.tab.master, a.tab.master_sh, quarter, load, store);
 }

@@ -69,12 +69,12 @@ class DeviceCircuit:
 class DeviceProver:
     """One GPU's context plus helpers to run the path on device-resident columns."""
 
-    def __init__(self, device_index: int = 0):
+    def __init__(self, device_index: int = 0, field=0):
         if not torch.cuda.is_available():
             raise RuntimeError("no GPU visible: the hot path has no CPU fallback")
         self.device = torch.device("cuda", device_index)
         torch.cuda.set_device(self.device)
-        self.ctx = Context(device_index)
+        self.ctx = Context(device_index, field)
         self.lib = self.ctx.lib
 
     # -- plumbing

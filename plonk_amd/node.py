@@ -21,13 +21,13 @@ class Node:
     """`exchange`: "rccl" (one GPU per rank, ncclAllToAll) or "copy" (device-to-device copies; several ranks may share
     a GPU, which is how the sharded paths are rehearsed on a single GPU)."""
 
-    def __init__(self, devices: Sequence[int], exchange: str = "rccl"):
+    def __init__(self, devices: Sequence[int], exchange: str = "rccl", field: int = 0):
         self.lib = _lib.load()
         self.devices = list(devices)
         arr = (C.c_int * len(self.devices))(*self.devices)
         h = C.c_void_p()
         mode = {"rccl": _lib.NODE_RCCL, "copy": _lib.NODE_COPY}[exchange]
-        rc = self.lib.plk_node_create(arr, len(self.devices), mode, C.byref(h))
+        rc = self.lib.plk_node_create_field(arr, len(self.devices), mode, field, C.byref(h))
         if rc != _lib.PLK_OK:
             raise PlonkError(rc, f"plk_node_create(devices={self.devices}, exchange={exchange}): {self.lib.plk_strerror(rc).decode()}")
         self.handle = h

@@ -24,10 +24,11 @@ from .api import AST_KINDS, GateEvaluationTable, PermutationTable
 SEED_BASE = 0x504C4F4E4B  # "PLONK"
 CIRCUIT_STRIDE = 1000003
 
-P_INT = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
-P_LIMBS = np.array([(P_INT >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
-ONE_MONT_INT = (1 << 256) % P_INT
-ONE_MONT = np.array([(ONE_MONT_INT >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+#: moduli of the fields the library is instantiated for, by field id (include/plonk_hip.h: PLK_FIELD_*)
+FIELD_MODULI = {
+    0: 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001,      # BLS12-381 Fr
+    1: (1 << 254) + 4707489544292117082687961190295928833,                        # Tweedle Fr (Tweedledee's scalar field)
+}
 
 _M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
 
@@ -42,42 +43,84 @@ def splitmix64(seed: int, count: int) -> np.ndarray:
         return z ^ (z >> np.uint64(31))
 
 
-def _geq_p(a: np.ndarray) -> np.ndarray:
-    """a >= p, limb-wise on (n, 4) uint64."""
-    ge = np.ones(a.shape[0], dtype=bool)
-    decided = np.zeros(a.shape[0], dtype=bool)
-    for i in (3, 2, 1, 0):
-        gt, lt = a[:, i] > P_LIMBS[i], a[:, i] < P_LIMBS[i]
-        ge = np.where(~decided & lt, False, ge)
-        decided |= gt | lt
-    return ge
+class FieldSpec:
+    """The host-side arithmetic the generators need, for one field: reduction of 256-bit integers below p and
+    conversions between Python integers and Montgomery limb rows."""
+
+    def __init__(self, field_id: int):
+        self.id = field_id
+        self.P_INT = FIELD_MODULI[field_id]
+        self.P_LIMBS = np.array([(self.P_INT >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+        self.ONE_MONT_INT = (1 << 256) % self.P_INT
+        self.ONE_MONT = np.array([(self.ONE_MONT_INT >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+        self.R_INV_INT = pow(1 << 256, -1, self.P_INT)
+        self._subtractions = (1 << 256) // self.P_INT          # a 256-bit integer is below (this + 1) p
+
+    def _geq_p(self, a: np.ndarray) -> np.ndarray:
+        """a >= p, limb-wise on (n, 4) uint64."""
+        ge = np.ones(a.shape[0], dtype=bool)
+        decided = np.zeros(a.shape[0], dtype=bool)
+        for i in (3, 2, 1, 0):
+            gt, lt = a[:, i] > self.P_LIMBS[i], a[:, i] < self.P_LIMBS[i]
+            ge = np.where(~decided & lt, False, ge)
+            decided |= gt | lt
+        return ge
+
+    def _sub_p(self, a: np.ndarray, mask: np.ndarray) -> np.ndarray:
+        out = a.copy()
+        borrow = np.zeros(a.shape[0], dtype=np.uint64)
+        with np.errstate(over="ignore"):
+            for i in range(4):
+                sub = np.where(mask, self.P_LIMBS[i], np.uint64(0))
+                d = a[:, i] - sub
+                b1 = (a[:, i] < sub).astype(np.uint64)
+                d2 = d - borrow
+                b2 = (d < borrow).astype(np.uint64)
+                out[:, i] = d2
+                borrow = b1 | b2
+        return out
+
+    def reduce_mod_p(self, a: np.ndarray) -> np.ndarray:
+        """(n, 4) uint64 256-bit integers -> reduced below p by conditional subtractions (2^256 < 3 p for BLS12-381 Fr,
+        < 4 p for the Tweedle field)."""
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        for _ in range(self._subtractions):
+            a = self._sub_p(a, self._geq_p(a))
+        return a
+
+    def random_elements(self, seed: int, n: int) -> np.ndarray:
+        return self.reduce_mod_p(splitmix64(seed, 4 * n).reshape(n, 4))
+
+    def ints_to_mont(self, values) -> np.ndarray:
+        out = np.empty((len(values), 4), dtype=np.uint64)
+        for i, v in enumerate(values):
+            m = (int(v) % self.P_INT) * self.ONE_MONT_INT % self.P_INT
+            for j in range(4):
+                out[i, j] = (m >> (64 * j)) & 0xFFFFFFFFFFFFFFFF
+        return out
+
+    def mont_to_ints(self, a: np.ndarray):
+        a = np.asarray(a, dtype=np.uint64).reshape(-1, 4)
+        return [sum(int(a[i, j]) << (64 * j) for j in range(4)) * self.R_INV_INT % self.P_INT for i in range(a.shape[0])]
+
+    def make_circuit(self, n: int, circuit_id: int = 0, kinds=AST_KINDS) -> "Circuit":
+        return make_circuit(n, circuit_id, kinds, field=self)
 
 
-def _sub_p(a: np.ndarray, mask: np.ndarray) -> np.ndarray:
-    out = a.copy()
-    borrow = np.zeros(a.shape[0], dtype=np.uint64)
-    with np.errstate(over="ignore"):
-        for i in range(4):
-            sub = np.where(mask, P_LIMBS[i], np.uint64(0))
-            d = a[:, i] - sub
-            b1 = (a[:, i] < sub).astype(np.uint64)
-            d2 = d - borrow
-            b2 = (d < borrow).astype(np.uint64)
-            out[:, i] = d2
-            borrow = b1 | b2
-    return out
+_FIELDS = {}
 
 
-def reduce_mod_p(a: np.ndarray) -> np.ndarray:
-    """(n, 4) uint64 256-bit integers -> reduced below p (2^256 < 3p, so two subtractions suffice)."""
-    a = np.ascontiguousarray(a, dtype=np.uint64)
-    for _ in range(2):
-        a = _sub_p(a, _geq_p(a))
-    return a
+def field(field_id: int = 0) -> FieldSpec:
+    if field_id not in _FIELDS:
+        _FIELDS[field_id] = FieldSpec(field_id)
+    return _FIELDS[field_id]
 
 
-def random_elements(seed: int, n: int) -> np.ndarray:
-    return reduce_mod_p(splitmix64(seed, 4 * n).reshape(n, 4))
+# the default field (BLS12-381 Fr) under the module's own names
+_F0 = field(0)
+P_INT, P_LIMBS, ONE_MONT_INT, ONE_MONT = _F0.P_INT, _F0.P_LIMBS, _F0.ONE_MONT_INT, _F0.ONE_MONT
+reduce_mod_p = _F0.reduce_mod_p
+random_elements = _F0.random_elements
 
 
 def random_permutation(seed: int, n: int) -> np.ndarray:
@@ -93,7 +136,8 @@ class Circuit:
     gamma: np.ndarray
 
 
-def make_circuit(n: int, circuit_id: int = 0, kinds=AST_KINDS) -> Circuit:
+def make_circuit(n: int, circuit_id: int = 0, kinds=AST_KINDS, field: FieldSpec = _F0) -> Circuit:
+    random_elements, ONE_MONT = field.random_elements, field.ONE_MONT
     base = SEED_BASE + CIRCUIT_STRIDE * circuit_id
     wires = [random_elements(base + k, n) for k in range(4)]
     sigmas = [random_permutation(base + 4 + k, n) for k in range(4)]
@@ -112,11 +156,6 @@ def make_circuit(n: int, circuit_id: int = 0, kinds=AST_KINDS) -> Circuit:
     if not gamma.any():
         gamma = ONE_MONT.copy()
     return Circuit(n, GateEvaluationTable(*wires, selectors=selectors), PermutationTable(*sigmas), beta, gamma)
-
-
-# ---- conversions between Python integers and limb rows (small inputs, tests and fixtures)
-
-R_INV_INT = pow(1 << 256, -1, P_INT)
 
 
 def make_node_ids(n: int, circuit_id: int = 0, leaves: int = 0):
@@ -160,15 +199,7 @@ def make_trace(n: int, circuit_id: int = 0, leaves: int = 0) -> FlatTrace:
     return FlatTrace(kind | (inputs << np.uint8(4)), ids, random_elements(base + 21, leaves + n))
 
 
-def ints_to_mont(values) -> np.ndarray:
-    out = np.empty((len(values), 4), dtype=np.uint64)
-    for i, v in enumerate(values):
-        m = (int(v) % P_INT) * ONE_MONT_INT % P_INT
-        for j in range(4):
-            out[i, j] = (m >> (64 * j)) & 0xFFFFFFFFFFFFFFFF
-    return out
-
-
-def mont_to_ints(a: np.ndarray):
-    a = np.asarray(a, dtype=np.uint64).reshape(-1, 4)
-    return [sum(int(a[i, j]) << (64 * j) for j in range(4)) * R_INV_INT % P_INT for i in range(a.shape[0])]
+# ---- conversions between Python integers and limb rows (small inputs, tests and fixtures), default field
+ints_to_mont = _F0.ints_to_mont
+mont_to_ints = _F0.mont_to_ints
+R_INV_INT = _F0.R_INV_INT

@@ -9,10 +9,10 @@ cd "$(dirname "$0")/.."
 name=$1; shift
 src=tools/ab_$name
 rm -rf "$src"; mkdir -p "$src"
-cp plonk_amd/csrc/*.cuh plonk_amd/csrc/capi.hip "$src"/
+cp plonk_amd/csrc/*.cuh plonk_amd/csrc/capi.hip plonk_amd/csrc/node.hip "$src"/
 for spec in "$@"; do
   f=${spec%%=*}; rev=${spec#*=}
   git show "$rev:plonk_amd/csrc/$f" > "$src/$f"
 done
-hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 $AB_FLAGS -shared -o "tools/bin/$name.so" "$src/capi.hip"
+hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 $AB_FLAGS -shared -o "tools/bin/$name.so" "$src/capi.hip" "$src/node.hip"
 echo "tools/bin/$name.so"

@@ -13,6 +13,7 @@ import csv
 import glob
 import json
 import os
+import re
 import shutil
 import sys
 from collections import OrderedDict, defaultdict
@@ -42,7 +43,7 @@ STEP = [l for groups in BY_GRID.values() for g in groups for l in g]
 
 def short(name):
     """'void plk::gp_apply_kernel<4>(unsigned long*, ...)' -> 'gp_apply_kernel'"""
-    base = name.split("(")[0].replace("plk::", "")
+    base = re.sub(r"plk(_field\d+)?::", "", name.split("(")[0])       # (the namespace carries the field's number)
     if base.startswith("void "):
         base = base[5:]
     return base.split("<")[0]
@@ -56,7 +57,7 @@ def grid_of(r):
 
 def labelled(rows, name_key):
     """yield (label, row) for the dispatches that belong to round-2+3 steps."""
-    rows = [r for r in rows if "plk::" in r[name_key].split("(")[0] and "table_kernel" not in r[name_key]]
+    rows = [r for r in rows if re.search(r"plk(_field\d+)?::", r[name_key].split("(")[0]) and "table_kernel" not in r[name_key]]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     grids = defaultdict(set)
     for r in rows:
