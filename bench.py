@@ -38,6 +38,11 @@ NTT_ROOFLINE_GELEM = HBM_PEAK_GBS / 64.0   # 64 algorithmic bytes per element pe
 # (153 v_mad_u64_u32 per product at the 31.4 T lane-ops/s of tools/ubench_valu.hip) would be 205 G products/s.
 VALU_PEAK_GPRODUCTS = 150.0
 VALU_MAD_ISSUE_BOUND_GPRODUCTS = 205.0
+# The same routine alone at 8 waves per SIMD (163.9; its precomputed-quotient form 178.6).  The in-tile steps do not
+# turn that occupancy into throughput: one stage per LDS round trip at 64 registers reaches 155.5 G products/s against
+# 154.9 for the library's radix-4 steps at 4 waves (tools/ubench_occupancy.hip, profiles/r03_ubench_occupancy.txt).
+VALU_PEAK_8_WAVES_GPRODUCTS = 163.9
+VALU_PEAK_8_WAVES_SHOUP_GPRODUCTS = 178.6
 
 
 def parse_args():
@@ -566,12 +571,18 @@ def main():
                              "unit": "G products/s", "frac": round(gp / VALU_PEAK_GPRODUCTS, 4),
                              "products_per_launch": dom["products"] / dom["launches"],
                              "mad_issue_bound": VALU_MAD_ISSUE_BOUND_GPRODUCTS,
+                             "frac_of_mad_issue_bound": round(gp / VALU_MAD_ISSUE_BOUND_GPRODUCTS, 4),
+                             "peak_8_waves": VALU_PEAK_8_WAVES_GPRODUCTS, "frac_of_8_wave_roof": round(gp / VALU_PEAK_8_WAVES_GPRODUCTS, 4),
+                             "peak_8_waves_precomputed_quotient": VALU_PEAK_8_WAVES_SHOUP_GPRODUCTS,
+                             "frac_of_8_wave_precomputed_quotient_roof": round(gp / VALU_PEAK_8_WAVES_SHOUP_GPRODUCTS, 4),
                              "step_products": all_products,
                              "step_products_per_s_G": round(all_products / (ms_per_step * 1e-3) / 1e9, 1),
                              "note": "256-bit modular products of the launch (counted from its shape: in-tile butterflies, "
                                      "inter-pass twiddle, coset prescale, u64 conversion) over its measured duration; peak = the "
-                                     "same product routine alone in a kernel at the same occupancy (tools/ubench_shoup.hip). "
-                                     "This, not HBM, is the roof the transform kernels sit under"}
+                                     "same product routine alone in a kernel at the same occupancy, 4 waves per SIMD "
+                                     "(tools/ubench_shoup.hip); the 8-wave figures are the routine alone at that occupancy, which "
+                                     "the in-tile steps measured at it do not reach (tools/ubench_occupancy.hip: 155.5 against "
+                                     "154.9 G products/s). This, not HBM, is the roof the transform kernels sit under"}
         # whole-transform throughput of the extension (all launches of the N-point forward transform)
         lde = [r for r in prof if f"/ntt{args.log_n + args.blowup.bit_length() - 1}" in r["label"] or "/lde" in r["label"]]
         ntt = None
@@ -594,6 +605,8 @@ def main():
             "config": {"workload": f"round 2+3, n=2^{args.log_n}, N={args.blowup}n, S={S} selectors, 18 interpolations + "
                                    f"18 extensions (wires evaluated once), one circuit per GPU per step",
                        "field": "BLS12-381 Fr", "circuits_per_step": world},
+            "host_call_note": "inputs and outputs resident in HBM; the reference-shaped call on host vectors (plk_round23) moves 772 MB "
+                              "over PCIe per call and takes 15.7 ms page-locked / 26 ms pageable at this size (DESIGN.md section 5)",
             "proofs_per_s": round(world / (ms_per_step * 1e-3), 3),
             "step_alg_bytes": alg_bytes_step,
             "step_frac_of_hbm_roofline": round(alg_bytes_step / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if alg_bytes_step else None,

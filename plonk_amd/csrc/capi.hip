@@ -507,6 +507,8 @@ int launch_ntt(plk_ctx* ctx, hipStream_t s, const uint64_t* const* in, const uin
     const uint64_t tiles = 1ull << (log_n - lr - a.log_c);
     if (tiles * slots > 0x7fffffffull) return fail(ctx, PLK_ERR_ARG, "transform batch too large for one launch");
     a.slots = (uint32_t)slots;
+    // tiles of fewer than 4 columns (runs below 128 bytes): 4 / columns neighbouring positions side by side in the order
+    a.log_group = std::max(0, std::min(2 - a.log_c, log_inner - a.log_c));
     // + the inter-pass twiddle (two products through the two-level table), + the coset prescale in the first pass
     const double per_elem = tile_products(lr, p == 0 && quarter_in) + (plan->tab.tw_full[p] ? 1.0 : 2.0) + ((p == 0 && cosets) ? 1.0 : 0.0);
     ProfScope ps(ctx, s, "ntt_pass_kernel" + tag + "/p" + std::to_string(p), alg_share, per_elem * elems + (p == 0 ? u64_products : 0.0));

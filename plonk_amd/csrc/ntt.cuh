@@ -25,6 +25,15 @@
 
 namespace plk {
 
+#ifndef PLK_TILE_GROUPING
+#define PLK_TILE_GROUPING 1      // workgroup order of the non-final passes: see ntt_pass_kernel
+#endif
+#ifndef PLK_FINAL_XCD_ORDER
+#define PLK_FINAL_XCD_ORDER 0    // measurement knob: XCD-contiguous workgroup order in the last pass
+#endif
+#ifndef PLK_COSET_MAJOR
+#define PLK_COSET_MAJOR 0
+#endif
 #ifndef PLK_NT_PASS_STORE
 #define PLK_NT_PASS_STORE 0      // measurement knob: non-temporal stores of a non-final pass's outputs
 #endif
@@ -342,6 +351,7 @@ struct NttPassArgs {
   int cosets;
   const uint32_t* prescale;
   uint32_t slots;    // transforms in this launch; the grid is 1-D with tiles * slots workgroups
+  int log_group;     // log2 of the neighbouring tile positions kept together in the workgroup order (0 = none)
   NttU64 u64;        // first pass only
 };
 
@@ -359,8 +369,24 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void ntt_pass_kernel(const NttPassA
   const Tile tile(lds_raw);
   uint32_t wg = blockIdx.x;
   if ((gridDim.x & 7u) == 0) wg = (wg & 7u) * (gridDim.x >> 3) + (wg >> 3);
+#if PLK_TILE_GROUPING
+  // Tiles narrower than a 128-byte line (fewer than 4 columns) leave part of every line they touch to the tile
+  // positions next to them: 2^a.log_group neighbouring positions are therefore made neighbours in the order as well
+  // (position-group major, slot, position within the group minor), so that the pieces of a line are asked for - and
+  // written - by workgroups that run side by side on one XCD, and meet in its L2.
+  const uint32_t in_group = wg & ((1u << a.log_group) - 1u);
+  const uint32_t gs = wg >> a.log_group;
+  const uint32_t group_id = gs / a.slots;
+  int slot = (int)(gs - group_id * a.slots);
+  const uint32_t tile_id = (group_id << a.log_group) + in_group;
+#if PLK_COSET_MAJOR
+  // measurement knob: the cosets of one column far apart in the order (coset-major) instead of side by side
+  if (a.first && a.cosets) { const int b = (int)a.slots / a.cosets; slot = (slot % b) * a.cosets + slot / b; }
+#endif
+#else
   const uint32_t tile_id = wg / a.slots;
   const int slot = (int)(wg - tile_id * a.slots);
+#endif
   const int poly = (a.first && a.cosets) ? slot / a.cosets : slot;
   const uint64_t* __restrict__ in = a.batch.src(poly);
   uint64_t* __restrict__ out = a.batch.dst(slot);
@@ -427,14 +453,26 @@ template <bool BIG, int LR = 0>
 __global__ __launch_bounds__(NTT_THREADS, 4) void ntt_final_kernel(const NttFinalArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const Tile tile(lds_raw);
+#if PLK_FINAL_XCD_ORDER
+  // Hardware deals consecutive workgroup ids to the 8 XCDs in turn; un-swizzled, one XCD walks a contiguous range of
+  // (slot, tile) pairs, so the neighbouring tiles that write the two halves of one 128-byte output line (tiles of 2
+  // columns) run side by side on one XCD and the halves leave its L2 as one line.
+  uint32_t wg = blockIdx.x + gridDim.x * blockIdx.y;
+  const uint32_t total = gridDim.x * gridDim.y;
+  if ((total & 7u) == 0) wg = (wg & 7u) * (total >> 3) + (wg >> 3);
+  const int slot = (int)(wg / gridDim.x);
+  const uint32_t tile_x = wg - (uint32_t)slot * gridDim.x;
+#else
   const int slot = blockIdx.y;   // slots share nothing here, so the plain 2-D order is kept
+  const uint32_t tile_x = blockIdx.x;
+#endif
   const int col = a.cosets ? slot / a.cosets : slot;
   const int poly = a.first ? col : slot;
   const uint64_t* __restrict__ in = a.batch.src(poly);
   uint64_t* __restrict__ out = a.batch.dst(col) + (a.cosets ? (uint64_t)(slot % a.cosets) * a.coset_stride : 0);
   const int log_c = LR ? NTT_TILE_LOG - LR : a.log_c, log_r = LR ? LR : a.log_r;
-  const uint64_t k2 = blockIdx.x & ((1u << a.log_r2) - 1);
-  const uint64_t k1_0 = (uint64_t)(blockIdx.x >> a.log_r2) << log_c;
+  const uint64_t k2 = tile_x & ((1u << a.log_r2) - 1);
+  const uint64_t k1_0 = (uint64_t)(tile_x >> a.log_r2) << log_c;
   const uint32_t kind = a.first ? a.batch.kind_of(poly) : (uint32_t)NTT_IN_FIELD;
 
   const bool scaled = a.tab.scale != nullptr;   // single-pass inverse transforms only: the record is read where it is used, so that
