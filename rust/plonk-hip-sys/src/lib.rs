@@ -21,6 +21,10 @@ pub const PLK_ERR_HIP: c_int = -6;
 pub const PLK_ERR_ARG: c_int = -7;
 pub const PLK_ERR_NOMEM: c_int = -8;
 
+pub const PLK_FIELD_BLS12_381_FR: c_int = 0;
+pub const PLK_FIELD_TWEEDLE_FR: c_int = 1;
+pub const PLK_NUM_FIELDS: usize = 2;
+
 pub const PLK_NUM_WIRES: usize = 4;
 pub const PLK_NUM_SELECTORS: usize = 9;
 
@@ -86,6 +90,13 @@ extern "C" {
     pub fn plk_round23(ctx: *mut plk_ctx, wires: *const *const u64, sel: *const *const u64, sigma: *const *const u64,
                        n: usize, big_n: usize, beta: *const u64, gamma: *const u64, z_shift: usize,
                        z_out: *mut u64, gate_out: *mut u64, perm_out: *mut u64) -> c_int;
+
+    // ---- fields: a context computes in the field it was created for (plk_ctx_create = field 0)
+    pub fn plk_ctx_create_field(device: c_int, field_id: c_int, out: *mut *mut plk_ctx) -> c_int;
+    pub fn plk_ctx_field(ctx: *const plk_ctx) -> c_int;
+    pub fn plk_field_name(field_id: c_int) -> *const c_char;
+    pub fn plk_field_constants_of(field_id: c_int, modulus: *mut u64, one: *mut u64, r2: *mut u64) -> c_int;
+    pub fn plk_node_create_field(devices: *const c_int, ranks: usize, exchange: c_int, field_id: c_int, out: *mut *mut plk_node) -> c_int;
 
     // ---- device memory for a host without a HIP binding (no counterpart in the reference) ----
     pub fn plk_dev_alloc(ctx: *mut plk_ctx, bytes: usize, out: *mut *mut c_void) -> c_int;

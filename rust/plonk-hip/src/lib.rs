@@ -5,8 +5,11 @@
 //! `plonk-hip-sys`.  NOT compiled in this repository's environment (no Rust toolchain, no arkworks crates
 //! there); the C++ and Python mirrors of the same ABI are what the test suite runs.
 //!
-//! The library implements one field, the BLS12-381 scalar field.  The functions stay generic over `F` as in
-//! the reference; `check_field::<F>()` panics for any other `F`.  Elements cross the boundary as the 4 x u64
+//! The library is instantiated for the BLS12-381 scalar field (the default; every measured and checked figure is
+//! for it) and for the scalar field of Tweedledee (the reference names `ark_tweedle::Fr`, src/main.rs:3; that
+//! instantiation's generator and root of unity are self-derived, not checked against ark-ff).  The functions stay
+//! generic over `F` as in the reference; `check_field::<F>()` picks the instantiation by `F::characteristic()` and
+//! panics for any other `F`.  Elements cross the boundary as the 4 x u64
 //! Montgomery limbs that ARE the memory of ark-ff 0.3 `Fp256<P>` (`x.0 .0`), so slices are passed by pointer.
 
 use std::collections::HashMap;
@@ -105,7 +108,8 @@ unsafe impl Send for Ctx {}
 /// One context per process on GPU `PLONK_HIP_DEVICE` (default 0), created at the first call.  A context must
 /// not be used from two threads at once, so every call holds this lock; the reference's functions are
 /// re-entrant and callers may use any thread.
-static CTX: Mutex<Option<Ctx>> = Mutex::new(None);
+/// (one per field the library is instantiated for, indexed by the `PLK_FIELD_*` number)
+static CTX: Mutex<[Option<Ctx>; sys::PLK_NUM_FIELDS]> = Mutex::new([None, None]);
 
 /// Runs `f` on the context under the lock.  `f` reports a failure as the text of the panic the reference would
 /// raise (`check` builds it, reading the context's error string and row while the lock is still held); the panic
@@ -113,23 +117,23 @@ static CTX: Mutex<Option<Ctx>> = Mutex::new(None);
 /// zero denominator, a sigma index, a length: `catch_unwind`, `#[should_panic]` tests sharing one binary) never
 /// poison the lock.  A lock poisoned by a panic in the caller's own closure (`build_and_convert`'s builder) is
 /// taken over all the same: the C context stays valid after any error return.
-fn with_ctx(f: impl FnOnce(*mut sys::plk_ctx) -> Result<(), String>) {
+fn with_ctx(field: usize, f: impl FnOnce(*mut sys::plk_ctx) -> Result<(), String>) {
     let failure = {
         let mut guard = CTX.lock().unwrap_or_else(|e| e.into_inner());
         let mut create_failure = None;
-        if guard.is_none() {
+        if guard[field].is_none() {
             let device = std::env::var("PLONK_HIP_DEVICE").ok().and_then(|s| s.parse().ok()).unwrap_or(0);
             let mut p: *mut sys::plk_ctx = ptr::null_mut();
-            let rc = unsafe { sys::plk_ctx_create(device, &mut p) };
+            let rc = unsafe { sys::plk_ctx_create_field(device, field as i32, &mut p) };
             if rc == sys::PLK_OK {
-                *guard = Some(Ctx(p));
+                guard[field] = Some(Ctx(p));
             } else {
-                create_failure = Some(format!("plk_ctx_create(device = {}) failed: {}", device, strerror(rc)));
+                create_failure = Some(format!("plk_ctx_create_field(device = {}, field = {}) failed: {}", device, field, strerror(rc)));
             }
         }
         match create_failure {
             Some(msg) => Err(msg),
-            None => f(guard.as_ref().unwrap().0),
+            None => f(guard[field].as_ref().unwrap().0),
         }
     }; // the guard is gone here
     if let Err(msg) = failure {
@@ -164,14 +168,20 @@ fn check(ctx: *mut sys::plk_ctx, rc: i32, length_message: &str) -> Result<(), St
     }
 }
 
-/// Panics unless `F` is the field the library implements with the memory layout it expects.
-fn check_field<F: Field>() {
-    let mut modulus = [0u64; 4];
-    unsafe { sys::plk_field_constants(modulus.as_mut_ptr(), ptr::null_mut(), ptr::null_mut()) };
-    assert!(
-        size_of::<F>() == 32 && F::characteristic() == &modulus[..] && F::extension_degree() == 1,
-        "libplonk_hip implements the BLS12-381 scalar field (4 x u64 Montgomery limbs) only"
-    );
+/// The library's number (`PLK_FIELD_*`) for `F`: the instantiation whose modulus is `F::characteristic()`, for a
+/// 32-byte prime field (4 x u64 Montgomery limbs, the memory of ark-ff 0.3 `Fp256`).  Panics for any other `F`.
+/// Field 0 is the BLS12-381 scalar field; field 1 the scalar field of Tweedledee, whose root of unity the library
+/// derives from the generator 5 - results agree with ark-poly's only if ark-ff's parameters for it use that generator.
+fn check_field<F: Field>() -> usize {
+    assert!(size_of::<F>() == 32 && F::extension_degree() == 1, "libplonk_hip implements 256-bit prime fields (4 x u64 Montgomery limbs) only");
+    for id in 0..sys::PLK_NUM_FIELDS {
+        let mut modulus = [0u64; 4];
+        let rc = unsafe { sys::plk_field_constants_of(id as i32, modulus.as_mut_ptr(), ptr::null_mut(), ptr::null_mut()) };
+        if rc == sys::PLK_OK && F::characteristic() == &modulus[..] {
+            return id;
+        }
+    }
+    panic!("libplonk_hip is not instantiated for this field (it has the BLS12-381 scalar field and the Tweedledee scalar field)");
 }
 
 fn limbs<F>(v: &[F]) -> *const u64 {
@@ -259,11 +269,11 @@ fn with_node(f: impl FnOnce(*mut sys::plk_node) -> Result<(), String>) -> bool {
 
 /// src/polynomial_utils.rs:18-33.
 pub fn evaluations_to_dense_polynomial<F: FftField>(evals: &[F], domain: &GeneralEvaluationDomain<F>) -> DensePolynomial<F> {
-    check_field::<F>();
+    let field = check_field::<F>();
     assert_eq!(evals.len(), domain.size(), "Evaluation length must match the domain size");
     let mut coeffs = vec![F::zero(); domain.size()];
-    // a large transform on a configured node: sharded over its GPUs
-    if domain.size() >= node_min_size()
+    // a large transform on a configured node (BLS12-381 Fr): sharded over its GPUs
+    if field == 0 && domain.size() >= node_min_size()
         && with_node(|node| {
             let rc = unsafe { sys::plk_node_ntt_host(node, limbs(evals), evals.len(), 1, limbs_mut(&mut coeffs)) };
             if rc == sys::PLK_OK {
@@ -275,7 +285,7 @@ pub fn evaluations_to_dense_polynomial<F: FftField>(evals: &[F], domain: &Genera
     {
         return DensePolynomial::from_coefficients_vec(coeffs);
     }
-    with_ctx(|ctx| {
+    with_ctx(field, |ctx| {
         let rc = unsafe { sys::plk_intt(ctx, limbs(evals), evals.len(), domain.size(), limbs_mut(&mut coeffs)) };
         check(ctx, rc, "Evaluation length must match the domain size")
     });
@@ -300,7 +310,7 @@ pub fn gate_evaluation_table_to_gate_polynomial<F: FftField>(
     table: &GateEvaluationTable<F>,
     coset_domain: &GeneralEvaluationDomain<F>,
 ) -> GatePolynomials<F> {
-    check_field::<F>();
+    let field = check_field::<F>();
     let n = coset_domain.size();
     let cols = [&table.input1, &table.input2, &table.input3, &table.output];
     for c in cols.iter() {
@@ -320,7 +330,7 @@ pub fn gate_evaluation_table_to_gate_polynomial<F: FftField>(
         let wire_out_ptrs: Vec<*mut u64> = wire_out.iter_mut().map(|v| limbs_mut(v)).collect();
         let sel_out_ptrs: Vec<*mut u64> =
             sel_out.iter_mut().map(|o| o.as_mut().map_or(ptr::null_mut(), |v| limbs_mut(v))).collect();
-        with_ctx(|ctx| {
+        with_ctx(field, |ctx| {
             let rc = unsafe { sys::plk_gate_polys(ctx, wires.as_ptr(), sel.as_ptr(), n, n, wire_out_ptrs.as_ptr(), sel_out_ptrs.as_ptr()) };
             check(ctx, rc, "Evaluation length must match the domain size")
         });
@@ -343,7 +353,7 @@ pub fn gate_evaluation_table_to_gate_polynomial<F: FftField>(
 
 /// src/execution_trace.rs:357-431.
 pub fn build_gate_constraint_evaluation_polynomial<F: FftField>(gate_poly: &GatePolynomials<F>, domain: &GeneralEvaluationDomain<F>) -> Vec<F> {
-    check_field::<F>();
+    let field = check_field::<F>();
     let big_n = domain.size();
     let polys = [&gate_poly.input1, &gate_poly.input2, &gate_poly.input3, &gate_poly.output];
     let n_coeffs = polys.iter().map(|p| p.coeffs.len()).chain(gate_poly.selectors.values().map(|p| p.coeffs.len())).max().unwrap_or(0);
@@ -355,7 +365,7 @@ pub fn build_gate_constraint_evaluation_polynomial<F: FftField>(gate_poly: &Gate
     }
     let sel: Vec<*const u64> = sel_bufs.iter().map(|o| o.as_ref().map_or(ptr::null(), |v| limbs(v))).collect();
     let mut out = vec![F::zero(); big_n];
-    with_ctx(|ctx| {
+    with_ctx(field, |ctx| {
         // more coefficients than domain points is the length panic inside evaluate_over_domain_by_ref
         let rc = unsafe { sys::plk_gate_constraints(ctx, wires.as_ptr(), sel.as_ptr(), n_coeffs, big_n, limbs_mut(&mut out)) };
         check(ctx, rc, "polynomial degree exceeds the evaluation domain")
@@ -372,7 +382,7 @@ pub fn build_grand_product_evaluation_polynomial<F: Field>(
     beta: F,
     gamma: F,
 ) -> Vec<F> {
-    check_field::<F>();
+    let field = check_field::<F>();
     let n = evaluation_table.input1.len();
     let t = evaluation_table;
     let p = permutation_table;
@@ -383,7 +393,7 @@ pub fn build_grand_product_evaluation_polynomial<F: Field>(
     let wires = [limbs(&t.input1), limbs(&t.input2), limbs(&t.input3), limbs(&t.output)];
     let sigma = [index_ptr(&p.sigma1), index_ptr(&p.sigma2), index_ptr(&p.sigma3), index_ptr(&p.sigma_output)];
     let mut z = vec![F::one(); n + 1];
-    with_ctx(|ctx| {
+    with_ctx(field, |ctx| {
         let rc = unsafe { sys::plk_grand_product(ctx, wires.as_ptr(), sigma.as_ptr(), n, one_elem(&beta), one_elem(&gamma), limbs_mut(&mut z)) };
         check(ctx, rc, "")
     });
@@ -410,7 +420,7 @@ pub fn build_permutation_polynomials_with_last<F: FftField>(
     gamma: F,
     coset_domain: &GeneralEvaluationDomain<F>,
 ) -> (PermutationPolynomials<F>, F) {
-    check_field::<F>();
+    let field = check_field::<F>();
     let n = coset_domain.size();
     let t = evaluation_table;
     let p = permutation_table;
@@ -424,7 +434,7 @@ pub fn build_permutation_polynomials_with_last<F: FftField>(
     let mut z_last = F::zero();
     {
         let sig_ptrs: Vec<*mut u64> = sig_out.iter_mut().map(|v| limbs_mut(v)).collect();
-        with_ctx(|ctx| {
+        with_ctx(field, |ctx| {
             let rc = unsafe {
                 sys::plk_perm_polys(ctx, wires.as_ptr(), sigma.as_ptr(), n, n, one_elem(&beta), one_elem(&gamma), sig_ptrs.as_ptr(),
                                     limbs_mut(&mut z_coeffs), &mut z_last as *mut F as *mut u64)
@@ -451,7 +461,7 @@ pub fn build_permutation_constraint_evaluation_polynomial<F: FftField>(
     gamma: F,
     evaluation_domain: &GeneralEvaluationDomain<F>,
 ) -> Vec<F> {
-    check_field::<F>();
+    let field = check_field::<F>();
     let big_n = evaluation_domain.size();
     let sig = [&polynomials.sigma1, &polynomials.sigma2, &polynomials.sigma3, &polynomials.sigma_output];
     let wir = [&gate_polynomials.input1, &gate_polynomials.input2, &gate_polynomials.input3, &gate_polynomials.output];
@@ -462,7 +472,7 @@ pub fn build_permutation_constraint_evaluation_polynomial<F: FftField>(
     let sig_ptrs: Vec<*const u64> = sig_bufs.iter().map(|v| limbs(v)).collect();
     let wir_ptrs: Vec<*const u64> = wir_bufs.iter().map(|v| limbs(v)).collect();
     let mut out = vec![F::zero(); big_n];
-    with_ctx(|ctx| {
+    with_ctx(field, |ctx| {
         let rc = unsafe {
             sys::plk_perm_constraints(ctx, limbs(&z), sig_ptrs.as_ptr(), wir_ptrs.as_ptr(), n_coeffs, big_n, one_elem(&beta), one_elem(&gamma), 1,
                                       limbs_mut(&mut out))
@@ -486,7 +496,7 @@ pub fn prove_round23<F: FftField>(
     coset_domain: &GeneralEvaluationDomain<F>,
     evaluation_domain: &GeneralEvaluationDomain<F>,
 ) -> (Vec<F>, Vec<F>, Vec<F>) {
-    check_field::<F>();
+    let field = check_field::<F>();
     let (n, big_n) = (coset_domain.size(), evaluation_domain.size());
     let t = evaluation_table;
     let p = permutation_table;
@@ -503,7 +513,7 @@ pub fn prove_round23<F: FftField>(
     let mut z = vec![F::zero(); n + 1];
     let mut gate = vec![F::zero(); big_n];
     let mut perm = vec![F::zero(); big_n];
-    with_ctx(|ctx| {
+    with_ctx(field, |ctx| {
         let rc = unsafe {
             sys::plk_round23(ctx, wires.as_ptr(), sel.as_ptr(), sigma.as_ptr(), n, big_n, one_elem(&beta), one_elem(&gamma), 1,
                              limbs_mut(&mut z), limbs_mut(&mut gate), limbs_mut(&mut perm))
