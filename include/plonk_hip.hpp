@@ -52,10 +52,12 @@ struct SigmaOutOfRange : Error { using Error::Error; };
 
 class Context {
  public:
-  explicit Context(int device = 0) {
-    const int rc = plk_ctx_create(device, &ctx_);
-    if (rc != PLK_OK) throw Error(rc, std::string("plk_ctx_create: ") + plk_strerror(rc));
+  // `field`: PLK_FIELD_BLS12_381_FR (the default) or PLK_FIELD_TWEEDLE_FR; every call on the context computes in it
+  explicit Context(int device = 0, int field = PLK_FIELD_BLS12_381_FR) {
+    const int rc = plk_ctx_create_field(device, field, &ctx_);
+    if (rc != PLK_OK) throw Error(rc, std::string("plk_ctx_create_field: ") + plk_strerror(rc));
   }
+  int field() const { return plk_ctx_field(ctx_); }
   ~Context() { plk_ctx_destroy(ctx_); }
   Context(const Context&) = delete;
   Context& operator=(const Context&) = delete;
@@ -454,6 +456,48 @@ inline GateEvaluationTable build_gate_evaluation_table(const FlatTrace& trace, c
   ctx.check(plk_gate_table_fill(ctx.get(), trace.row_ops.data(), ids, n, detail::ptr(trace.node_values), trace.node_values.size(),
                                 default_val.data(), wires, sel));
   return t;
+}
+
+// ---- several GPUs behind the same interface (plk_node_*: no counterpart in the reference) -----------------------
+
+// G ranks in this process, one GPU each.  `exchange`: PLK_NODE_RCCL (one GPU per rank) or PLK_NODE_COPY
+// (device-to-device copies; several ranks may share a GPU).
+class Node {
+ public:
+  Node(const std::vector<int>& devices, int exchange, int field = PLK_FIELD_BLS12_381_FR) {
+    const int rc = plk_node_create_field(devices.data(), devices.size(), exchange, field, &node_);
+    if (rc != PLK_OK) throw Error(rc, std::string("plk_node_create_field: ") + plk_strerror(rc));
+  }
+  ~Node() { plk_node_destroy(node_); }
+  Node(const Node&) = delete;
+  Node& operator=(const Node&) = delete;
+  plk_node* get() const { return node_; }
+  size_t ranks() const { return plk_node_ranks(node_); }
+  void check(int rc) const {
+    if (rc == PLK_OK) return;
+    std::string msg = plk_node_last_error(node_);
+    throw Error(rc, msg.empty() ? std::string(plk_strerror(rc)) : msg);
+  }
+
+ private:
+  plk_node* node_ = nullptr;
+};
+
+// evaluations_to_dense_polynomial (src/polynomial_utils.rs:18-33) as ONE transform sharded over the node's GPUs
+inline DensePolynomial evaluations_to_dense_polynomial(const std::vector<Fr>& evals, const GeneralEvaluationDomain& domain, Node& node) {
+  if (evals.size() != domain.size()) throw LengthMismatch(PLK_ERR_LENGTH, "Evaluation length must match the domain size");
+  std::vector<Fr> coeffs(domain.size());
+  node.check(plk_node_ntt_host(node.get(), detail::ptr(evals), domain.size(), 1, detail::ptr(coeffs)));
+  return DensePolynomial::from_coefficients_vec(std::move(coeffs));
+}
+
+// DensePolynomial::evaluate_over_domain_by_ref on the node (coefficients zero-padded to the domain size on the host)
+inline std::vector<Fr> evaluate_over_domain(const DensePolynomial& p, const GeneralEvaluationDomain& domain, Node& node) {
+  if (p.coeffs.size() > domain.size()) throw LengthMismatch(PLK_ERR_LENGTH, "polynomial degree exceeds the evaluation domain");
+  std::vector<Fr> evals(domain.size());
+  const std::vector<Fr> c = detail::padded(p, domain.size());
+  node.check(plk_node_ntt_host(node.get(), detail::ptr(c), domain.size(), 0, detail::ptr(evals)));
+  return evals;
 }
 
 }  // namespace plonk_hip

@@ -283,6 +283,61 @@ static void test_commitment() {
   CHECK(threw);
 }
 
+// One transform sharded over four ranks of a node (the ranks share GPU 0 here and exchange by device-to-device
+// copies), through the reference's own function shape, against the C restatement and the one-GPU call.
+static void test_node_transform() {
+  std::printf("test_node_transform\n");
+  Node node({0, 0, 0, 0}, PLK_NODE_COPY);
+  CHECK(node.ranks() == 4);
+  for (size_t n : {size_t(1) << 10, size_t(1) << 16}) {
+    sm_state = 99 + n;
+    const std::vector<Fr> evals = random_column(n);
+    const DensePolynomial p = evaluations_to_dense_polynomial(evals, GeneralEvaluationDomain(n), node);
+    std::vector<Fr> want(n);
+    CHECK(orc_intt(evals[0].data(), n, n, want[0].data()) == 0);
+    CHECK(padded(p, n) == want);
+    CHECK(padded(evaluations_to_dense_polynomial(evals, GeneralEvaluationDomain(n)), n) == want);
+    CHECK(evaluate_over_domain(p, GeneralEvaluationDomain(n), node) == evals);
+  }
+  bool threw = false;
+  try { evaluations_to_dense_polynomial(std::vector<Fr>(24, from_int(1)), GeneralEvaluationDomain(24), node); } catch (const Error& e) { threw = e.code == PLK_ERR_NOT_POW2; }
+  CHECK(threw);
+  threw = false;
+  try { Node bad({0, 0}, PLK_NODE_RCCL); } catch (const Error& e) { threw = e.code == PLK_ERR_ARG; }   // RCCL wants one GPU per rank
+  CHECK(threw);
+}
+
+// A context over the second field: the transform of the constant one is (n, 0, 0, ...) in any field, the one of
+// (0, 1, 0, ...) is the powers of that field's root of unity - which differ between the fields - and the inverse
+// transform returns the input.
+static void test_second_field() {
+  std::printf("test_second_field\n");
+  Context tw(0, PLK_FIELD_TWEEDLE_FR);
+  CHECK(tw.field() == PLK_FIELD_TWEEDLE_FR && Context::global().field() == PLK_FIELD_BLS12_381_FR);
+  uint64_t one0[4], one1[4], p1[4];
+  CHECK(plk_field_constants_of(PLK_FIELD_BLS12_381_FR, nullptr, one0, nullptr) == PLK_OK);
+  CHECK(plk_field_constants_of(PLK_FIELD_TWEEDLE_FR, p1, one1, nullptr) == PLK_OK);
+  CHECK(p1[3] == 0x4000000000000000ull && p1[0] == 0x842cafd400000001ull);
+  const size_t n = 1 << 12;
+  const Fr o1{one1[0], one1[1], one1[2], one1[3]}, zero{0, 0, 0, 0};
+  std::vector<Fr> delta(n, zero); delta[1] = o1;
+  DensePolynomial x; x.coeffs = delta;                       // the polynomial X
+  const std::vector<Fr> pw = [&] { std::vector<Fr> e(n); tw.check(plk_ntt(tw.get(), plonk_hip::detail::ptr(delta), n, n, plonk_hip::detail::ptr(e))); return e; }();
+  CHECK(pw[0] == o1 && !(pw[1] == o1) && !(pw[1] == zero));
+  // omega^(n/2) = -1: pw[n/2] + 1 = 0 mod p, checked through the library's own product: (pw[n/2])^2 = 1
+  std::vector<Fr> back(n);
+  tw.check(plk_intt(tw.get(), plonk_hip::detail::ptr(pw), n, n, plonk_hip::detail::ptr(back)));
+  CHECK(back == delta);
+  // the same input on the first field's context gives other points (another modulus, another root)
+  std::vector<Fr> d0(n, zero); d0[1] = Fr{one0[0], one0[1], one0[2], one0[3]};
+  std::vector<Fr> pw0(n);
+  Context::global().check(plk_ntt(Context::global().get(), plonk_hip::detail::ptr(d0), n, n, plonk_hip::detail::ptr(pw0)));
+  CHECK(!(pw0[1] == pw[1]));
+  // commitments live in BLS12-381 G1 only
+  uint64_t xy[12];
+  CHECK(plk_msm_g1(tw.get(), plonk_hip::detail::ptr(delta), 4, xy) == PLK_ERR_ARG);
+}
+
 int main() {
   test_evaluations_to_dense_polynomial();
   test_round_2_and_3_function_by_function(4, 16, 9);
@@ -293,6 +348,8 @@ int main() {
   test_tables_from_a_trace();
   test_quotient_step();
   test_commitment();
+  test_node_transform();
+  test_second_field();
   std::printf("%d failure(s)\n", failures);
   return failures;
 }
