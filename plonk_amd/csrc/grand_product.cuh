@@ -187,7 +187,10 @@ __device__ __forceinline__ F9 gp_invert(const F9& d_rprime) {
 }
 
 // Kernel A: local quotient products L_j -> z_after[j] (= z[j+1] up to the block carry), block ratios r_b -> ratio[b].
-__global__ __launch_bounds__(GP_THREADS, 4) void gp_local_z_kernel(GpCols cols, uint64_t n, GpConsts k9,
+#ifndef PLK_GP_WAVES
+#define PLK_GP_WAVES 4
+#endif
+__global__ __launch_bounds__(GP_THREADS, PLK_GP_WAVES) void gp_local_z_kernel(GpCols cols, uint64_t n, GpConsts k9,
                                                                    uint64_t* z_after, uint64_t* z0, uint64_t* ratio, GpStatus* status) {
   __shared__ F9 lds[GP_THREADS / 64];
   __shared__ F9 edge[GP_THREADS / 64];
