@@ -60,6 +60,9 @@ def parse_args():
                          "through the library's native node layer (plk_node_ntt: ONE process, --gpus ranks, RCCL all-to-all). round23-sharded: ONE proof over all GPUs. "
                          "batch: --circuits independent circuits dealt round-robin (config 5 with --log-n 18 --circuits 64)")
     ap.add_argument("--circuits", type=int, default=64)
+    ap.add_argument("--field", type=int, default=0, choices=[0, 1],
+                    help="0: BLS12-381 Fr (the headline). 1: the second instantiation, Tweedle Fr (round23 workload only; not the headline, "
+                         "no CPU comparison unless --cpu-sample-log-n is reachable)")
     ap.add_argument("--cpu-sample-log-n", type=int, default=20,
                     help="rows of the CPU-baseline run (log2); below --log-n the time is scaled by the row count")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -74,7 +77,7 @@ def parse_args():
     return args
 
 
-def cpu_baseline(log_n_full: int, blowup: int, sample_log_n: int):
+def cpu_baseline(log_n_full: int, blowup: int, sample_log_n: int, field: int = 0):
     """The C restatement of the reference algorithm (oracle/plonk_oracle.c) timed on this host on circuit 0 of
     2^sample_log_n rows (the whole workload when that is log_n_full, else scaled linearly in the number of rows).
     Returns (the bench line's object, the circuit, the oracle's (z, gate, perm)): the caller checks the GPU's
@@ -83,12 +86,13 @@ def cpu_baseline(log_n_full: int, blowup: int, sample_log_n: int):
     import c_oracle as co
     from plonk_amd import synth
     ns = 1 << sample_log_n
-    c = synth.make_circuit(ns, circuit_id=0)
-    threads = min(co.num_threads(), 16)
-    co.set_num_threads(threads)
-    t0 = time.perf_counter()
-    ref = co.round23(c.table.wires(), c.table.selectors, c.perm.columns(), blowup * ns, c.beta, c.gamma)
-    dt = time.perf_counter() - t0
+    c = synth.field(field).make_circuit(ns, circuit_id=0)
+    with co.use_field(field):
+        threads = min(co.num_threads(), 16)
+        co.set_num_threads(threads)
+        t0 = time.perf_counter()
+        ref = co.round23(c.table.wires(), c.table.selectors, c.perm.columns(), blowup * ns, c.beta, c.gamma)
+        dt = time.perf_counter() - t0
     scale = float(1 << (log_n_full - sample_log_n))
     scaled = f"; scaled x{int(scale)} by row count (ignores the log factor of the transforms)" if scale != 1 else "; the full workload, unscaled"
     return {
@@ -488,10 +492,12 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     n, N = 1 << args.log_n, args.blowup << args.log_n
 
-    prover = DeviceProver(local_rank)
+    prover = DeviceProver(local_rank, field=args.field)
     if args.workload != "round23":
+        if args.field != 0:
+            sys.exit("bench.py: --field applies to the round23 workload only")
         return other_workloads(args, prover, dist, rank, world)
-    circuit = synth.make_circuit(n, circuit_id=rank)
+    circuit = synth.field(args.field).make_circuit(n, circuit_id=rank)
     dc = prover.upload(circuit)
     out = (prover.empty(n + 1), prover.empty(N), prover.empty(N))
 
@@ -604,7 +610,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"round 2+3, n=2^{args.log_n}, N={args.blowup}n, S={S} selectors, 18 interpolations + "
                                    f"18 extensions (wires evaluated once), one circuit per GPU per step",
-                       "field": "BLS12-381 Fr", "circuits_per_step": world},
+                       "field": ("BLS12-381 Fr", "Tweedle Fr (second instantiation: constants self-derived, not the headline field)")[args.field],
+                       "circuits_per_step": world},
             "host_call_note": "inputs and outputs resident in HBM; the reference-shaped call on host vectors (plk_round23) moves 772 MB "
                               "over PCIe per call and takes 15.7 ms page-locked / 26 ms pageable at this size (DESIGN.md section 5)",
             "proofs_per_s": round(world / (ms_per_step * 1e-3), 3),
@@ -620,7 +627,7 @@ def main():
             # its results IN FULL (the timed run's own outputs when the sample is the whole workload)
             from plonk_amd.device import to_host
             sample_log_n = min(args.cpu_sample_log_n, args.log_n)
-            line["cpu_baseline"], c_ref, ref = cpu_baseline(args.log_n, args.blowup, sample_log_n)
+            line["cpu_baseline"], c_ref, ref = cpu_baseline(args.log_n, args.blowup, sample_log_n, args.field)
             if sample_log_n == args.log_n:
                 got = out
             else:

@@ -99,6 +99,10 @@ def test_node_rccl_one_rank(prover):
             back = node.ntt(out, N, inverse=True)
             node.sync()
             assert torch.equal(back[0], x)
+            N1 = 1 << ((log_n + 1) // 2)
+            blk = node.ntt([x], N, natural_output=False)       # two exchanges: [k1][k2] = X[k1 + N1 k2]
+            node.sync()
+            assert torch.equal(blk[0].view(N1, N // N1, 4), direct.view(N // N1, N1, 4).permute(1, 0, 2))
     finally:
         node.close()
 
@@ -169,3 +173,12 @@ def test_device_memory_helpers(ctx):
     ctx.check(lib.plk_dev_download(ctx.handle, st, y.ctypes.data, p, y.nbytes))
     lib.plk_dev_free(ctx.handle, p)
     assert np.array_equal(y, co.intt(x, 1 << 10))
+    # 16 MiB of ordinary (pageable) memory: the threaded staging copy, both directions
+    big = synth.random_elements(6, 1 << 19)
+    ctx.check(lib.plk_dev_alloc(ctx.handle, big.nbytes, C.byref(p)))
+    ctx.check(lib.plk_dev_upload(ctx.handle, st, p, big.ctypes.data, big.nbytes))
+    back = np.zeros_like(big)
+    ctx.check(lib.plk_dev_download(ctx.handle, st, back.ctypes.data, p, back.nbytes))
+    lib.plk_dev_free(ctx.handle, p)
+    assert np.array_equal(back, big)
+    assert lib.plk_dev_upload(ctx.handle, st, None, big.ctypes.data, 64) == _lib.PLK_ERR_ARG
