@@ -54,7 +54,7 @@ def parse_args():
                     help="log2 of the number of rows (default: 20; 24 for --workload ntt and 18 for --workload batch, the sizes "
                          "of the sharded-transform and batched-proof configurations)")
     ap.add_argument("--blowup", type=int, default=4, help="evaluation domain = blowup * n")
-    ap.add_argument("--workload", default="round23", choices=["round23", "ntt", "node-ntt", "round23-sharded", "batch", "tables", "quotient", "msm"],
+    ap.add_argument("--workload", default="round23", choices=["round23", "ntt", "node-ntt", "node-round23", "round23-sharded", "batch", "tables", "quotient", "msm"],
                     help="round23: the headline metric (default). ntt: ONE four-step transform of 2^log-n points sharded over "
                          "the GPUs (config 4 with --log-n 24), one process per GPU over torch.distributed. node-ntt: the same transform "
                          "through the library's native node layer (plk_node_ntt: ONE process, --gpus ranks, RCCL all-to-all). round23-sharded: ONE proof over all GPUs. "
@@ -422,6 +422,72 @@ def node_ntt(args) -> int:
     return 0 if ok else 6
 
 
+def node_round23(args) -> int:
+    """--workload node-round23: rounds 2+3 of ONE circuit of 2^log-n rows over --gpus ranks held by THIS process
+    (plk_node_round23: the 18 columns dealt to the ranks, one all-to-all, the constraints on N / G points per rank), its
+    pieces compared in full with the single-GPU call on GPU 0."""
+    import torch
+    from plonk_amd import synth
+    from plonk_amd.device import DeviceCircuit, DeviceProver
+    from plonk_amd.node import Node
+    G, n = args.gpus, 1 << args.log_n
+    N = 4 * n
+    share = os.environ.get("PLONK_BENCH_SHARE_GPU") == "1"
+    devices = [0] * G if share else list(range(G))
+    exchange = os.environ.get("PLONK_BENCH_NODE_EXCHANGE", "copy" if share else "rccl")
+    prover = DeviceProver(0)
+    dc0 = prover.upload(synth.make_circuit(n, circuit_id=0))
+    node = Node(devices, exchange=exchange)
+
+    def on(dc, dev):
+        return DeviceCircuit(dc.n, [w.to(dev).clone() for w in dc.wires], {k: v.to(dev).clone() for k, v in dc.selectors.items()},
+                             [t.to(dev).clone() for t in dc.sigma], dc.beta, dc.gamma)
+
+    copies = [on(dc0, node.device(g)) for g in range(G)]
+    outs = [tuple(torch.empty((rows, 4), dtype=torch.int64, device=node.device(g)) for rows in (n + 1, N // G, N // G)) for g in range(G)]
+    node.round23(copies, N, outs)
+    z, gate, perm = prover.round23(dc0, N)
+    prover.status()
+    ok = all(torch.equal(o[0].to(prover.device), z) for o in outs) \
+        and torch.equal(torch.cat([o[1].to(prover.device) for o in outs]), gate) \
+        and torch.equal(torch.cat([o[2].to(prover.device) for o in outs]), perm)
+    for _ in range(args.warmup):
+        node.round23(copies, N, outs)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        node.round23(copies, N, outs)           # returns when every rank is done
+    ms = (time.perf_counter() - t0) * 1e3 / args.steps
+    slots = -(-18 // G)
+    line = {"metric": f"prover round 2+3 time at n=2^{args.log_n} (one proof over the node's ranks)", "value": round(ms, 4), "unit": "ms", "n_gpus": G,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": False, "scaling": "strong",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": f"rounds 2+3 of ONE circuit, n=2^{args.log_n}, N=4n, its 18 columns dealt to {G} rank(s) in one process "
+                                   f"(plk_node_round23, exchange: {exchange}, devices {devices}); one all-to-all of "
+                                   f"{(G - 1) * slots * (N // G + 1) * 32 / 2**20:.1f} MiB sent per rank; Z computed on every rank"},
+            "matches_single_gpu": bool(ok)}
+    node.close()
+    print(json.dumps(line), flush=True)
+    return 0 if ok else 6
+
+
+def node_round23_extra(world: int, limit: int):
+    """Extra figure of a multi-GPU run, outside `value`: ONE proof over all the GPUs through the native node layer, in a
+    child process of rank 0 like `node_ntt_extra`."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK",
+                                                             "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "node-round23", "--gpus", str(world), "--steps", "5", "--warmup", "2"]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=limit)
+    except subprocess.TimeoutExpired:
+        return {"error": f"did not finish within {limit} s"}
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if not lines:
+        return {"error": f"exit status {r.returncode}: " + (r.stderr.strip().splitlines() or ["no output"])[-1][:300]}
+    d = json.loads(lines[-1])
+    return {"what": d["config"]["workload"], "ms": d["ms_per_step"], "matches_single_gpu": d["matches_single_gpu"]}
+
+
 def node_ntt_extra(world: int, limit: int):
     """Extra figure of a multi-GPU run, outside `value`: the sharded 2^24-point transform through the library's native
     node layer (one process driving all the GPUs, RCCL bound by the library itself), run as a child process of rank 0
@@ -461,6 +527,8 @@ def main():
     args = parse_args()
     if args.workload == "node-ntt":
         sys.exit(node_ntt(args))              # one process holds every rank
+    if args.workload == "node-round23":
+        sys.exit(node_round23(args))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
     import torch
@@ -684,13 +752,16 @@ def main():
         # the other ranks wait at the barrier below
         line["node_ntt"] = node_ntt_extra(world, args.four_step_limit)
         node_failed = "error" in line["node_ntt"] or line["node_ntt"].get("round_trip_bit_exact") is False
+        if args.workload == "round23" and args.field == 0:
+            line["node_round23"] = node_round23_extra(world, args.four_step_limit)
+            node_failed = node_failed or "error" in line["node_round23"] or line["node_round23"].get("matches_single_gpu") is False
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if node_failed:
-        print("bench.py: the native node layer's sharded transform failed: " + json.dumps(line["node_ntt"]), file=sys.stderr, flush=True)
+        print("bench.py: the native node layer failed: " + json.dumps({k: line.get(k) for k in ("node_ntt", "node_round23")}), file=sys.stderr, flush=True)
         sys.exit(7)
     if line is not None and line.get("matches_cpu") is False:
         print("bench.py: the GPU's outputs differ from the CPU restatement: " + json.dumps(line["matches_cpu_detail"]), file=sys.stderr, flush=True)

@@ -478,6 +478,15 @@ typedef struct {
 } plk_circuit_io;
 int plk_node_round23_batch(plk_node* node, const plk_circuit_io* circuits, size_t count, size_t n, size_t N, size_t z_shift);
 
+/* ONE proof over the node's G ranks (independent polynomials sharded over the GPUs): per_rank[g] holds the SAME
+ * circuit's columns resident on rank g's GPU.  The 18 columns (4 wires, the selectors present, 4 sigma, Z) are dealt
+ * to the ranks for interpolation and extension to N = 4 n points (N / G >= z_shift >= 1), one all-to-all turns "my
+ * columns, all points" into "all columns, my points" (with a z_shift-point halo of Z), and every rank evaluates both
+ * constraint vectors on its range: per_rank[g].z_out receives the whole Z (n + 1 elements, computed on every rank),
+ * gate_out / perm_out the points [g N / G, (g + 1) N / G) of the vectors plk_round23 returns (N / G elements each).
+ * Returns when every rank is done; data-dependent failures come back as for plk_round23. */
+int plk_node_round23(plk_node* node, const plk_circuit_io* per_rank, size_t n, size_t N, size_t z_shift);
+
 #ifdef __cplusplus
 }
 #endif

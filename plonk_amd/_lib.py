@@ -46,7 +46,7 @@ NODE_COPY = 1
 
 
 class CircuitIO(C.Structure):
-    """plk_circuit_io: the columns and outputs of one circuit of plk_node_round23_batch (device addresses)."""
+    """plk_circuit_io: the columns and outputs of one circuit of plk_node_round23_batch / plk_node_round23 (device addresses)."""
     _fields_ = [("wires", C.c_void_p * NUM_WIRES), ("sel", C.c_void_p * NUM_SELECTORS), ("sigma", C.c_void_p * NUM_WIRES),
                 ("beta", C.c_uint64 * 4), ("gamma", C.c_uint64 * 4),
                 ("z_out", C.c_void_p), ("gate_out", C.c_void_p), ("perm_out", C.c_void_p)]
@@ -127,6 +127,7 @@ SIGNATURES = {
     "plk_node_ntt_host": (C.c_int, [C.c_void_p, u64p, C.c_size_t, C.c_int, u64p]),
     "plk_node_sync": (C.c_int, [C.c_void_p]),
     "plk_node_round23_batch": (C.c_int, [C.c_void_p, C.POINTER(CircuitIO), C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t]),
+    "plk_node_round23": (C.c_int, [C.c_void_p, C.POINTER(CircuitIO), C.c_size_t, C.c_size_t, C.c_size_t]),
     "plk_dev_to_montgomery": (C.c_int, [C.c_void_p, C.c_void_p, u64p, C.c_size_t, u64p]),
     "plk_dev_from_montgomery": (C.c_int, [C.c_void_p, C.c_void_p, u64p, C.c_size_t, u64p]),
 }

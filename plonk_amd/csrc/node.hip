@@ -135,8 +135,9 @@ struct Rank {
   hipStream_t stream = nullptr;           // the context's own stream
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};   // "my blocks of exchange k have been pushed"
   hipEvent_t done = nullptr;              // "my part of the last call has finished and my output is complete"
-  void* buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // A, B, C; D, E = shards of plk_node_ntt_host
-  size_t cap[5] = {0, 0, 0, 0, 0};
+  // A, B, C; D, E = shards of plk_node_ntt_host; F, G = send and receive buffers of plk_node_round23
+  void* buf[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t cap[7] = {0, 0, 0, 0, 0, 0, 0};
   ncclComm_t comm = nullptr;
   int rc = PLK_OK;
   std::string err;
@@ -481,6 +482,81 @@ int plk_node_round23_batch(plk_node* node, const plk_circuit_io* circuits, size_
   if (first < 0) return PLK_OK;
   const Rank& r = node->r[(size_t)first % G];
   return node_fail(node, r.rc, "plk_node_round23_batch, circuit " + std::to_string(first) + " (rank " + std::to_string((size_t)first % G) + "): " + r.err);
+}
+
+// ONE proof over the node's ranks (columns dealt to the ranks for interpolation and extension, one all-to-all, the
+// constraints on N / G points per rank).  Column numbering: wires 0-3, selectors 4-12, sigma 13-16, Z 17; the columns
+// present are dealt round-robin, rank g taking the ones at positions g, g + G, ... of that list.
+int plk_node_round23(plk_node* node, const plk_circuit_io* per_rank, size_t n, size_t N, size_t z_shift) {
+  if (!node) return PLK_ERR_ARG;
+  node->last_error.clear();
+  if (!per_rank) return node_fail(node, PLK_ERR_ARG, "null pointer");
+  const size_t G = node->r.size();
+  if (log2_exact(n) < 2 || N != 4 * n) return node_fail(node, PLK_ERR_ARG, "plk_node_round23 takes the extended domain N = 4 n, n a power of two >= 4");
+  if (N % G) return node_fail(node, PLK_ERR_ARG, "the ranks must divide the evaluation domain");
+  const size_t chunk = N / G;
+  if (z_shift == 0 || z_shift > chunk) return node_fail(node, PLK_ERR_ARG, "z_shift must be between 1 and N / ranks");
+  // the columns present (the same on every rank: taken from rank 0's table, checked against the others)
+  int present[18]; size_t np = 0;
+  for (int c = 0; c < 18; ++c) {
+    const bool on = c < 4 || c >= 13 || per_rank[0].sel[c - 4] != nullptr;
+    if (on) present[np++] = c;
+  }
+  for (size_t g = 0; g < G; ++g) {
+    const plk_circuit_io& c = per_rank[g];
+    for (int k = 0; k < 4; ++k) if (!c.wires[k] || !c.sigma[k]) return node_fail(node, PLK_ERR_ARG, "null column pointer");
+    for (int k = 0; k < 9; ++k) if ((c.sel[k] != nullptr) != (per_rank[0].sel[k] != nullptr)) return node_fail(node, PLK_ERR_ARG, "the ranks disagree on which selectors are present");
+    if (!c.z_out || !c.gate_out || !c.perm_out) return node_fail(node, PLK_ERR_ARG, "null output pointer");
+  }
+  const size_t slots = (np + G - 1) / G;                    // columns per rank, at most
+  const size_t piece = chunk + z_shift;                     // a range's points followed by the next z_shift (halo)
+  const size_t block = slots * piece;                       // elements per (source, destination) pair
+  int rc = ensure_buffers(node, 5, 6, G * block * ELEM);
+  if (rc) return rc;
+  node->workers.run([&](size_t g) {
+    Rank& me = node->r[g];
+    const plk_circuit_io& c = per_rank[g];
+    me.rc = PLK_OK; me.err.clear();
+    bool ok = HIP_OK(hipSetDevice(me.device));
+    hipStream_t s = me.stream;
+    char *send = (char*)me.buf[5], *recv = (char*)me.buf[6];
+    if (ok && node->have_done)
+      for (size_t h = 0; h < G && ok; ++h) ok = HIP_OK(hipStreamWaitEvent(s, node->r[h].done, 0));
+    // Z on every rank (a third of a millisecond at 2^20 rows; replicated, it needs no exchange of its own)
+    if (ok) ok = PLK_OKAY(plk_dev_grand_product(me.ctx, s, c.wires, c.sigma, n, c.beta, c.gamma, c.z_out));
+    // my columns: interpolation and extension, written as [destination][slot][its points + halo]
+    const uint64_t* cols[18]; uint32_t kinds[18]; uint64_t* outs[18]; size_t mine = 0;
+    for (size_t i = g; i < np; i += G) {
+      const int col = present[i];
+      cols[mine] = col < 4 ? c.wires[col] : col < 13 ? c.sel[col - 4] : col < 17 ? c.sigma[col - 13] : c.z_out;
+      kinds[mine] = (col >= 13 && col < 17) ? PLK_INPUT_U64 : PLK_INPUT_FIELD;
+      outs[mine] = (uint64_t*)(send + mine * piece * ELEM);
+      ++mine;
+    }
+    if (ok && mine) ok = PLK_OKAY(plk_dev_extend4(me.ctx, s, cols, kinds, mine, n, nullptr, outs, chunk, block, z_shift));
+    // exchange: my slots, every rank's points -> every rank's slots, my points
+    if (node->exchange == PLK_NODE_RCCL) {
+      if (ok) ok = NCCL_OK(g_rccl.AllToAll(send, recv, block * 4, ncclUint64, me.comm, s));
+    } else {
+      for (size_t h = 0; h < G && ok; ++h)
+        ok = HIP_OK(hipMemcpyAsync((char*)node->r[h].buf[6] + g * block * ELEM, send + h * block * ELEM, block * ELEM, hipMemcpyDefault, s));
+      if (ok) ok = HIP_OK(hipEventRecord(me.ev[0], s));
+      node->barrier.wait();
+      for (size_t h = 0; h < G && ok; ++h)
+        if (h != g) ok = HIP_OK(hipStreamWaitEvent(s, node->r[h].ev[0], 0));
+    }
+    // column `present[i]` came from rank i % G in its slot i / G
+    const uint64_t* ev[18] = {nullptr};
+    for (size_t i = 0; i < np; ++i) ev[present[i]] = (const uint64_t*)(recv + ((i % G) * block + (i / G) * piece) * ELEM);
+    if (ok) ok = PLK_OKAY(plk_dev_gate_constraint_eval(me.ctx, s, ev, ev + 4, chunk, c.gate_out));
+    if (ok) ok = PLK_OKAY(plk_dev_perm_constraint_eval_range(me.ctx, s, ev[17], ev + 13, ev, chunk, g * chunk, c.beta, c.gamma, z_shift, c.perm_out));
+    if (ok) ok = HIP_OK(hipEventRecord(me.done, s));
+    // the data-dependent status (zero denominator, sigma index): waits for this rank's stream
+    const int st = plk_dev_status(me.ctx, s);
+    if (ok) (void)plk_ok(me, st, "plk_dev_status");
+  });
+  node->have_done = true;
+  return collect(node, "plk_node_round23");
 }
 
 }  // extern "C"

@@ -73,10 +73,7 @@ class Node:
                                               out.ctypes.data_as(_lib.u64p)))
         return out
 
-    def round23_batch(self, circuits: Sequence[DeviceCircuit], N: int, outs, z_shift: int = 1):
-        """Rounds 2+3 of `circuits[i]` (resident on rank i % G's GPU) into `outs[i] = (z, gate, perm)` tensors on the
-        same GPU; returns when all are done."""
-        n = circuits[0].n
+    def _io(self, circuits: Sequence[DeviceCircuit], outs):
         arr = (_lib.CircuitIO * len(circuits))()
         for io, dc, (z, g, p) in zip(arr, circuits, outs):
             for k in range(4):
@@ -91,5 +88,19 @@ class Node:
             io.z_out, io.gate_out, io.perm_out = z.data_ptr(), g.data_ptr(), p.data_ptr()
         for d in set(self.devices):
             torch.cuda.synchronize(d)
-        self.check(self.lib.plk_node_round23_batch(self.handle, arr, len(circuits), n, N, z_shift))
+        return arr
+
+    def round23_batch(self, circuits: Sequence[DeviceCircuit], N: int, outs, z_shift: int = 1):
+        """Rounds 2+3 of `circuits[i]` (resident on rank i % G's GPU) into `outs[i] = (z, gate, perm)` tensors on the
+        same GPU; returns when all are done."""
+        arr = self._io(circuits, outs)
+        self.check(self.lib.plk_node_round23_batch(self.handle, arr, len(circuits), circuits[0].n, N, z_shift))
+        return outs
+
+    def round23(self, copies: Sequence[DeviceCircuit], N: int, outs, z_shift: int = 1):
+        """Rounds 2+3 of ONE circuit over the G ranks: `copies[g]` is the circuit resident on rank g's GPU,
+        `outs[g] = (z of n + 1, gate of N / G, perm of N / G)` tensors there - rank g's range of the constraint vectors."""
+        assert len(copies) == self.G
+        arr = self._io(copies, outs)
+        self.check(self.lib.plk_node_round23(self.handle, arr, copies[0].n, N, z_shift))
         return outs

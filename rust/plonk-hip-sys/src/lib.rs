@@ -127,4 +127,5 @@ extern "C" {
     /// batched proofs: circuit i on rank i % ranks, all its pointers in that rank's GPU memory
     pub fn plk_node_round23_batch(node: *mut plk_node, circuits: *const plk_circuit_io, count: usize, n: usize, big_n: usize,
                                   z_shift: usize) -> c_int;
+    pub fn plk_node_round23(node: *mut plk_node, per_rank: *const plk_circuit_io, n: usize, big_n: usize, z_shift: usize) -> c_int;
 }

@@ -307,6 +307,30 @@ static void test_node_transform() {
   CHECK(threw);
 }
 
+// One proof over the four ranks of a node against the one-GPU call and, for Z, the C restatement.
+static void test_node_round23() {
+  std::printf("test_node_round23\n");
+  Node node({0, 0, 0, 0}, PLK_NODE_COPY);
+  const size_t n = 1 << 11, N = 4 * n;
+  const Circuit c = make_circuit(n, 4242);
+  const GeneralEvaluationDomain dn(n), dN(N);
+  for (size_t z_shift : {size_t(1), size_t(4)}) {
+    const Round23 one = prove_round23(c.table, c.perm, c.beta, c.gamma, dn, dN, z_shift);
+    const Round23 many = prove_round23(c.table, c.perm, c.beta, c.gamma, dn, dN, z_shift, node);
+    CHECK(many.z == one.z);
+    CHECK(many.gate_constraints == one.gate_constraints);
+    CHECK(many.permutation_constraints == one.permutation_constraints);
+    Ptrs p(c);
+    std::vector<Fr> z(n + 1);
+    int64_t bad = -1;
+    CHECK(orc_grand_product(p.wires, p.sigma, n, c.beta.data(), c.gamma.data(), z[0].data(), &bad) == 0);
+    CHECK(many.z == z);
+  }
+  bool threw = false;
+  try { prove_round23(c.table, c.perm, c.beta, c.gamma, dn, GeneralEvaluationDomain(2 * n), 1, node); } catch (const Error& e) { threw = e.code == PLK_ERR_ARG; }
+  CHECK(threw);
+}
+
 // A context over the second field: the transform of the constant one is (n, 0, 0, ...) in any field, the one of
 // (0, 1, 0, ...) is the powers of that field's root of unity - which differ between the fields - and the inverse
 // transform returns the input.
@@ -339,6 +363,7 @@ static void test_second_field() {
 }
 
 int main() {
+  std::setvbuf(stdout, nullptr, _IONBF, 0);        // the name of the running test is out before anything it does
   test_evaluations_to_dense_polynomial();
   test_round_2_and_3_function_by_function(4, 16, 9);
   test_round_2_and_3_function_by_function(1 << 10, 1 << 10, 9);     // "check" use: N = n
@@ -349,6 +374,7 @@ int main() {
   test_quotient_step();
   test_commitment();
   test_node_transform();
+  test_node_round23();
   test_second_field();
   std::printf("%d failure(s)\n", failures);
   return failures;

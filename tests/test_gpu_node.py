@@ -159,6 +159,61 @@ def test_node_round23_batch(prover):
         node.close()
 
 
+@pytest.mark.parametrize("G,kinds", [(1, None), (2, None), (4, ("Add", "Mul", "Const")), (8, None), (2, ())])
+def test_node_round23_one_proof_over_the_ranks(prover, G, kinds):
+    """plk_node_round23: the columns dealt to G ranks, one exchange, the constraints on N / G points per rank - the
+    ranks' pieces joined are the vectors of the CPU restatement, Z whole on every rank; several z_shift, and a second
+    call on the same node (its buffers reused)."""
+    from plonk_amd.api import AST_KINDS
+    n, N = 1 << 10, 1 << 12
+    node = Node([0] * G, exchange="copy")
+    try:
+        for rep, z_shift in enumerate((1, 4, N // G)):
+            c = synth.make_circuit(n, circuit_id=300 + G + rep, kinds=AST_KINDS if kinds is None else kinds)
+            copies = [prover.upload(c) for _ in range(G)]
+            outs = [(prover.empty(n + 1), prover.empty(N // G), prover.empty(N // G)) for _ in range(G)]
+            node.round23(copies, N, outs, z_shift=z_shift)
+            zr, gr, er = co.round23(c.table.wires(), c.table.selectors, c.perm.columns(), N, c.beta, c.gamma, z_shift=z_shift)
+            for z, _, _ in outs:
+                assert np.array_equal(to_host(z), zr)
+            assert np.array_equal(np.concatenate([to_host(o[1]) for o in outs]), gr), (G, z_shift)
+            assert np.array_equal(np.concatenate([to_host(o[2]) for o in outs]), er), (G, z_shift)
+    finally:
+        node.close()
+
+
+def test_node_round23_errors_and_large(prover):
+    """Argument errors of plk_node_round23; a zero denominator named with its rank; and 2^16 rows over four ranks against
+    the single-GPU call (itself checked against the oracle)."""
+    node = Node([0] * 4, exchange="copy")
+    try:
+        n, N = 1 << 16, 1 << 18
+        c = synth.make_circuit(n, circuit_id=321)
+        copies = [prover.upload(c) for _ in range(4)]
+        outs = [(prover.empty(n + 1), prover.empty(N // 4), prover.empty(N // 4)) for _ in range(4)]
+        with pytest.raises(pa.PlonkError) as ei:
+            node.round23(copies, 2 * n, outs)                        # only the 4n domain
+        assert ei.value.code == _lib.PLK_ERR_ARG
+        with pytest.raises(pa.PlonkError) as ei:
+            node.round23(copies, N, outs, z_shift=N // 4 + 1)        # halo longer than a rank's range
+        assert ei.value.code == _lib.PLK_ERR_ARG
+        node.round23(copies, N, outs, z_shift=4)
+        z, g, e = prover.round23(copies[0], N, z_shift=4)
+        torch.cuda.synchronize()
+        assert torch.equal(outs[2][0], z)
+        assert torch.equal(torch.cat([o[1] for o in outs]), g) and torch.equal(torch.cat([o[2] for o in outs]), e)
+        import plonk_oracle as po
+        beta, gamma = synth.mont_to_ints(c.beta)[0], synth.mont_to_ints(c.gamma)[0]
+        bad = synth.ints_to_mont([(-(beta * 9 + gamma)) % po.P]).view(np.int64)[0].copy()
+        for dc in copies:
+            dc.wires[1][9] = torch.from_numpy(bad).to(prover.device)
+        with pytest.raises(pa.PlonkError) as ei:
+            node.round23(copies, N, outs)
+        assert ei.value.code == _lib.PLK_ERR_ZERO_DENOMINATOR and "rank" in str(ei.value)
+    finally:
+        node.close()
+
+
 def test_device_memory_helpers(ctx):
     """plk_dev_alloc / upload / download / free: what a host without a HIP binding uses around the plk_dev_* calls."""
     lib = ctx.lib
