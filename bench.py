@@ -747,14 +747,24 @@ def main():
                 print("bench.py: the sharded transform's forward-then-inverse round trip did not return its input", file=sys.stderr, flush=True)
                 os._exit(6)
     node_failed = False
+    # The other ranks wait for rank 0's child processes on the HOST (a key in the rendezvous store): a collective
+    # barrier would sit on their GPUs as a spinning kernel beside the children's work.
+    store = dist.distributed_c10d._get_default_store() if (dist is not None and world > 1 and not args.no_four_step) else None
+    if store is not None and rank != 0:
+        import datetime
+        try:
+            store.wait(["plonk_bench_children_done"], datetime.timedelta(seconds=2 * args.four_step_limit + 60))
+        except Exception:   # noqa: BLE001 - rank 0 reports what happened to its children; this rank only stops waiting
+            pass
     if world > 1 and not args.no_four_step and rank == 0:
-        # the same transform once more through the native node layer (one child process over all the GPUs), while
-        # the other ranks wait at the barrier below
+        # the same transform once more through the native node layer (one child process over all the GPUs)
         line["node_ntt"] = node_ntt_extra(world, args.four_step_limit)
         node_failed = "error" in line["node_ntt"] or line["node_ntt"].get("round_trip_bit_exact") is False
         if args.workload == "round23" and args.field == 0:
             line["node_round23"] = node_round23_extra(world, args.four_step_limit)
             node_failed = node_failed or "error" in line["node_round23"] or line["node_round23"].get("matches_single_gpu") is False
+        if store is not None:
+            store.set("plonk_bench_children_done", "1")
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -150,3 +150,5 @@ def test_bench_starts_its_own_ranks():
     assert line["four_step"]["round_trip_bit_exact"] is True and line["four_step"]["ms"] > 0
     # and the same transform through the native node layer (a child process of rank 0: two ranks, copy exchange here)
     assert line["node_ntt"]["round_trip_bit_exact"] is True and line["node_ntt"]["ms"] > 0
+    # and one proof of 2^20 rows dealt over the node's two ranks, compared in full with the single-GPU call
+    assert line["node_round23"]["matches_single_gpu"] is True and line["node_round23"]["ms"] > 0
