@@ -96,6 +96,8 @@ constexpr size_t COPY_CHUNK = size_t(4) << 20;      // bytes per slot
 constexpr size_t COPY_MIN = size_t(8) << 20;        // below this a plain hipMemcpyAsync
 constexpr int COPY_WORKERS = 10;                    // at most; fewer on a host with fewer hardware threads
 
+namespace {
+
 struct CopyLane { void* slot[2] = {nullptr, nullptr}; hipStream_t st = nullptr; hipEvent_t ev[2] = {nullptr, nullptr}; };
 
 struct CopyPool {
@@ -145,6 +147,8 @@ struct CopyPool {
     threads.clear();
   }
 };
+
+}  // namespace
 
 struct plk_ctx {
   int field_id = PLK_FIELD_ID;   // FIRST member: dispatch.cpp reads it to pick the instantiation
@@ -1822,6 +1826,7 @@ int plk_ctx_create(int device, plk_ctx** out) {
     return PLK_ERR_HIP;
   }
   plk_ctx* ctx = new (std::nothrow) plk_ctx();
+  if (ctx) ctx->field_id = PLK_FIELD_ID;
   if (!ctx) return PLK_ERR_NOMEM;
   if (const char* e = getenv("PLONK_NTT_FIRST_RADIX_LOG")) ctx->first_radix_log = atoi(e);
   if (const char* e = getenv("PLONK_NTT_TWO_PASS_MAX_LOG")) ctx->two_pass_max_log = std::max(12, std::min(atoi(e), 2 * NTT_TILE_LOG));   // measurement knob

@@ -67,3 +67,26 @@ def test_limits_in_the_binding_are_the_header_s():
     assert _lib.NOALLOC_MAX_ROWS == 1 << shift
     assert _lib.MAX_BATCH == int(re.search(r"#define PLK_MAX_BATCH (\d+)", text).group(1))
     assert _lib.NUM_SELECTORS == int(re.search(r"#define PLK_NUM_SELECTORS (\d+)", text).group(1))
+
+
+def test_field_instantiations_share_no_symbols_of_their_own():
+    """The library holds one compiled instantiation of its entry points per field.  Apart from the C++ runtime's
+    and the standard library's own (identical wherever they are instantiated), no external symbol may be defined by
+    both objects: the linker would keep one definition for both, silently, and which one is a matter of inlining."""
+    import shutil
+    import subprocess
+    build = os.path.join(ROOT, "plonk_amd", "csrc", "build")
+    objs = [os.path.join(build, f"capi_f{k}.o") for k in (0, 1)]
+    if not all(os.path.exists(o) for o in objs) or not shutil.which("nm") or not shutil.which("c++filt"):
+        pytest.skip("the per-field objects are not in the tree (the library was built elsewhere)")
+
+    def defined(obj):
+        out = subprocess.run(["nm", "--defined-only", obj], capture_output=True, text=True, check=True).stdout
+        return {ln.split()[2] for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] in "WTVDBuR"}
+
+    both = sorted(defined(objs[0]) & defined(objs[1]))
+    names = subprocess.run(["c++filt"], input="\n".join(both), capture_output=True, text=True, check=True).stdout.splitlines()
+    allowed = ("std::", "void std::", "bool std::", "__gnu_cxx", "operator new", "typeinfo", "vtable", "guard variable",
+               "DW.ref.__gxx_personality_v0", "__clang_call_terminate", "decltype", "auto std::", "unsigned long std::", "int std::")
+    own = [n for n in names if not n.startswith(allowed)]
+    assert own == [], own
