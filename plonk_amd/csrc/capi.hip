@@ -53,6 +53,18 @@ struct GpScratch {
 #define PLK_FIXED_RADIX 1
 #endif
 
+// The library's own column buffers (the transforms' intermediate buffer, the coefficient vectors and coset planes of
+// rounds 2+3 and of the extension) are laid out this many 64-bit words further apart than their length: vectors of
+// 2^k elements at multiples of their own size put the same offset of every column into the same sets of an XCD's
+// L2, and a launch that walks 17 columns and 51 output slots at one offset at a time then evicts its own lines -
+// 128 bytes of skew per vector take a quarter of the memory-side reads and a tenth of the writes off the
+// extension's first pass (tools/ntt_harness.hip) and 2 % off its time.
+#ifndef PLK_PLANE_SKEW_WORDS
+#define PLK_PLANE_SKEW_WORDS 16
+#endif
+constexpr size_t PLANE_SKEW_WORDS = PLK_PLANE_SKEW_WORDS;
+static_assert(PLANE_SKEW_WORDS % 16 == 0, "vectors stay aligned to 128 bytes");
+
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
@@ -74,6 +86,7 @@ struct U64Opt {
   const Fe* scale = nullptr;
   uint64_t* conv_out = nullptr;
   int conv_first = 0;
+  size_t conv_stride = 0;   // 64-bit words between the converted columns (0 = n_in elements)
 };
 
 }  // namespace
@@ -408,7 +421,8 @@ int get_plan(plk_ctx* ctx, int log_n, bool inverse, hipStream_t s, NttPlan** out
 // batch <= NTT_MAX_BATCH) or as one base pointer plus a stride in elements.
 int launch_ntt(plk_ctx* ctx, hipStream_t s, const uint64_t* const* in, const uint32_t* kinds, size_t batch,
                size_t n_in, size_t N, bool inverse, uint64_t* const* out, size_t stride_in = 0, size_t stride_out = 0,
-               int cosets = 0, const char* tmp_slot = "ntt_tmp", const U64Opt* u64opt = nullptr) {
+               int cosets = 0, const char* tmp_slot = "ntt_tmp", const U64Opt* u64opt = nullptr, size_t coset_stride = 0) {
+  // coset_stride: 64-bit words between a column's coset outputs (0 = N elements)
   int log_n, rc;
   if ((rc = check_domain(ctx, N, &log_n))) return rc;
   if (n_in > N) return fail(ctx, PLK_ERR_LENGTH, "more input elements than domain points");
@@ -437,7 +451,7 @@ int launch_ntt(plk_ctx* ctx, hipStream_t s, const uint64_t* const* in, const uin
 
   NttU64 u64{};
   u64_record(u64opt ? u64opt->scale : nullptr, u64.rec);
-  if (u64opt && u64opt->conv_out) { u64.conv_out = u64opt->conv_out; u64.conv_stride = (uint64_t)n_in * 4; u64.conv_first = u64opt->conv_first; }
+  if (u64opt && u64opt->conv_out) { u64.conv_out = u64opt->conv_out; u64.conv_stride = u64opt->conv_stride ? (uint64_t)u64opt->conv_stride : (uint64_t)n_in * 4; u64.conv_first = u64opt->conv_first; }
   NttBatch user{};   // the caller's buffers
   const size_t n_ptr_in = stride_in ? 1 : batch, n_ptr_out = stride_out ? 1 : batch;
   for (size_t b = 0; b < n_ptr_in; ++b) {
@@ -454,7 +468,7 @@ int launch_ntt(plk_ctx* ctx, hipStream_t s, const uint64_t* const* in, const uin
   uint64_t* tmp = nullptr;
   if (plan->npass > 1) {
     void* p;
-    if ((rc = ws_get(ctx, tmp_slot, slots * N * ELEM, &p))) return rc;
+    if ((rc = ws_get(ctx, tmp_slot, slots * (N * ELEM + PLANE_SKEW_WORDS * 8), &p))) return rc;
     tmp = (uint64_t*)p;
   }
   const size_t lds_bytes = NTT_LDS_BYTES;
@@ -483,8 +497,8 @@ int launch_ntt(plk_ctx* ctx, hipStream_t s, const uint64_t* const* in, const uin
   }
   auto from_user = [&](NttBatch& b) { for (int i = 0; i < NTT_MAX_BATCH; ++i) { b.in[i] = user.in[i]; b.kind[i] = user.kind[i]; } b.stride_in = user.stride_in; };
   auto to_user = [&](NttBatch& b) { for (int i = 0; i < NTT_MAX_BATCH; ++i) b.out[i] = user.out[i]; b.stride_out = user.stride_out; };
-  auto from_tmp = [&](NttBatch& b) { b.in[0] = tmp; b.stride_in = (uint64_t)N * 4; b.kind[0] = NTT_IN_FIELD; };
-  auto to_tmp = [&](NttBatch& b) { b.out[0] = tmp; b.stride_out = (uint64_t)N * 4; };
+  auto from_tmp = [&](NttBatch& b) { b.in[0] = tmp; b.stride_in = (uint64_t)N * 4 + PLANE_SKEW_WORDS; b.kind[0] = NTT_IN_FIELD; };
+  auto to_tmp = [&](NttBatch& b) { b.out[0] = tmp; b.stride_out = (uint64_t)N * 4 + PLANE_SKEW_WORDS; };
   // non-final passes
   int log_inner = log_n;
   for (int p = 0; p + 1 < P; ++p) {
@@ -538,7 +552,7 @@ int launch_ntt(plk_ctx* ctx, hipStream_t s, const uint64_t* const* in, const uin
     a.first = P == 1;
     a.cosets = cosets;
     a.prescale = prescale;
-    a.coset_stride = (uint64_t)N * 4;
+    a.coset_stride = coset_stride ? (uint64_t)coset_stride : (uint64_t)N * 4;
     a.u64 = u64;
     if (P == 1) from_user(a.batch); else from_tmp(a.batch);
     to_user(a.batch);
@@ -567,23 +581,25 @@ int launch_extend4(plk_ctx* ctx, hipStream_t s, const uint64_t* const* cols, con
   if (chunk == 0) { chunk = 4 * n; chunk_stride = 4 * n; halo = 0; }
   if ((4 * n) % chunk || halo > chunk || chunk_stride < chunk + halo) return fail(ctx, PLK_ERR_ARG, "bad chunk layout");
   void *cp, *pp;
-  if ((rc = ws_get(ctx, "ext_coef", batch * n * ELEM, &cp))) return rc;
-  if ((rc = ws_get(ctx, "ext_planes", batch * 3 * n * ELEM, &pp))) return rc;
+  const size_t plane = n * 4 + PLANE_SKEW_WORDS;                   // 64-bit words from one n-element vector to the next
+  if ((rc = ws_get(ctx, "ext_coef", batch * plane * 8, &cp))) return rc;
+  if ((rc = ws_get(ctx, "ext_planes", batch * 3 * plane * 8, &pp))) return rc;
   uint64_t* coef[NTT_MAX_BATCH]; const uint64_t* coef_in[NTT_MAX_BATCH]; uint64_t* planes[NTT_MAX_BATCH];
   Interleave4Args a{};
   for (size_t b = 0; b < batch; ++b) {
     if (!cols[b] || !eval_out[b]) return fail(ctx, PLK_ERR_ARG, "null column pointer");
-    coef[b] = (coef_out && coef_out[b]) ? coef_out[b] : (uint64_t*)cp + b * n * 4;
+    coef[b] = (coef_out && coef_out[b]) ? coef_out[b] : (uint64_t*)cp + b * plane;
     coef_in[b] = coef[b];
-    planes[b] = (uint64_t*)pp + b * 3 * n * 4;
+    planes[b] = (uint64_t*)pp + b * 3 * plane;
     a.plane0[b] = cols[b];
     a.raw_index[b] = kinds && kinds[b] == NTT_IN_U64;
     a.out[b] = eval_out[b];
   }
   a.planes = (const uint64_t*)pp;
+  a.plane = plane;
   a.chunk = chunk; a.chunk_stride = chunk_stride; a.halo = halo;
   if ((rc = launch_ntt(ctx, s, cols, kinds, batch, n, n, true, coef))) return rc;
-  if ((rc = launch_ntt(ctx, s, coef_in, nullptr, batch, n, n, false, planes, 0, 0, 3))) return rc;
+  if ((rc = launch_ntt(ctx, s, coef_in, nullptr, batch, n, n, false, planes, 0, 0, 3, "ntt_tmp", nullptr, plane))) return rc;
   ProfScope ps(ctx, s, "interleave4_kernel", 2.0 * 128.0 * (double)n * (double)batch);
   hipLaunchKernelGGL(interleave4_kernel, dim3((unsigned)((4 * n + EW_THREADS - 1) / EW_THREADS), (unsigned)batch), dim3(EW_THREADS), 0, s, a,
                      (uint64_t)n);
@@ -930,20 +946,23 @@ int launch_perm_eval(plk_ctx* ctx, hipStream_t s, const uint64_t* z, const uint6
 struct R23Ws {
   uint64_t *coef = nullptr, *eval = nullptr, *z = nullptr;
   size_t n = 0, N = 0;
-  uint64_t* col_coef(int c) const { return coef + (size_t)c * n * 4; }
+  size_t plane() const { return n * 4 + PLANE_SKEW_WORDS; }                  // 64-bit words from one n-element vector to the next
+  uint64_t* col_coef(int c) const { return coef + (size_t)c * plane(); }
   uint64_t* col_eval(int c) const { return eval + (size_t)c * N * 4; }
-  uint64_t* col_cos(int c) const { return eval + (size_t)c * 3 * n * 4; }   // planes 1..3 of column c
+  uint64_t* col_cos(int c) const { return eval + (size_t)c * 3 * plane(); }  // planes 1..3 of column c
   // coset form (N = 4n) only, behind the 18 columns' planes: beta * F::from(sigma_k[j]), the trace-domain plane of the
   // scaled sigma columns (r23_sigma_group writes it, r23_perm reads it)
-  uint64_t* sigma_plane0(int k) const { return eval + ((size_t)54 + (size_t)k) * n * 4; }
+  uint64_t* sigma_plane0(int k) const { return eval + ((size_t)54 + (size_t)k) * plane(); }
 };
 
 int r23_workspace(plk_ctx* ctx, size_t n, size_t N, uint64_t* z_out, R23Ws* ws) {
   constexpr int NCOL = 18;
   void *coef_p, *eval_p, *z_p;
   int rc;
-  if ((rc = ws_get(ctx, "r23_coef", (size_t)NCOL * n * ELEM, &coef_p))) return rc;
-  if ((rc = ws_get(ctx, "r23_eval", (size_t)NCOL * N * ELEM, &eval_p))) return rc;
+  const size_t skewed = n * ELEM + PLANE_SKEW_WORDS * 8;          // one n-element vector and its skew
+  if ((rc = ws_get(ctx, "r23_coef", (size_t)NCOL * skewed, &coef_p))) return rc;
+  // 18 vectors of N elements (plain form) or 54 coset planes and 4 scaled sigma planes of n elements (coset form)
+  if ((rc = ws_get(ctx, "r23_eval", std::max((size_t)NCOL * N * ELEM, (size_t)(3 * NCOL + 4) * skewed), &eval_p))) return rc;
   if ((rc = ws_get(ctx, "r23_z", (n + 1) * ELEM, &z_p))) return rc;
   ws->coef = (uint64_t*)coef_p; ws->eval = (uint64_t*)eval_p; ws->z = z_out ? z_out : (uint64_t*)z_p;
   ws->n = n; ws->N = N;
@@ -959,7 +978,7 @@ int r23_extend_group(plk_ctx* ctx, hipStream_t s, const R23Ws& ws, const uint64_
   for (size_t b = 0; b < m; ++b) { in[b] = cols[b]; out[b] = ws.col_coef(col_of[b]); }
   if ((rc = launch_ntt(ctx, s, in, kinds, m, ws.n, ws.n, true, out, 0, 0, 0, tmp_slot, u64opt))) return rc;
   for (size_t b = 0; b < m; ++b) { in[b] = ws.col_coef(col_of[b]); out[b] = ws.col_cos(col_of[b]); }
-  return launch_ntt(ctx, s, in, nullptr, m, ws.n, ws.n, false, out, 0, 0, 3, tmp_slot);
+  return launch_ntt(ctx, s, in, nullptr, m, ws.n, ws.n, false, out, 0, 0, 3, tmp_slot, nullptr, ws.plane());
 }
 
 // The sigma columns (positions first .. first + 3 of a group, raw indices): in the coset form they are transformed
@@ -968,7 +987,7 @@ int r23_extend_group(plk_ctx* ctx, hipStream_t s, const R23Ws& ws, const uint64_
 struct SigmaScale {
   Fe beta; U64Opt opt;
   SigmaScale(const R23Ws& ws, const uint64_t beta_[4], int first) : beta(fe_from_limbs64(beta_)) {
-    opt.scale = &beta; opt.conv_out = ws.sigma_plane0(0); opt.conv_first = first;
+    opt.scale = &beta; opt.conv_out = ws.sigma_plane0(0); opt.conv_first = first; opt.conv_stride = ws.plane();
   }
 };
 
@@ -989,7 +1008,7 @@ int r23_gate(plk_ctx* ctx, hipStream_t s, const R23Ws& ws, const uint64_t* const
   for (int k = 0; k < 9; ++k) { const bool on = sel && sel[k]; g.s0[k] = on ? sel[k] : nullptr; g.s[k] = on ? ws.col_cos(4 + k) : nullptr; ncols += on; }
   ProfScope ps(ctx, s, "gate_constraint_coset_kernel", 32.0 * ncols * (double)ws.N, 7.0 * (double)ws.N);
   hipLaunchKernelGGL(gate_constraint_coset_kernel, dim3((unsigned)((ws.N + EW_THREADS - 1) / EW_THREADS)), dim3(EW_THREADS), 0, s, g,
-                     (uint64_t)ws.n, gate_out);
+                     (uint64_t)ws.n, (uint64_t)ws.plane(), gate_out);
   HIP_TRY(ctx, hipGetLastError());
   return PLK_OK;
 }
@@ -1003,7 +1022,7 @@ int r23_perm(plk_ctx* ctx, hipStream_t s, const R23Ws& ws, const uint64_t* const
   for (int k = 0; k < 4; ++k) { pc.sig0[k] = ws.sigma_plane0(k); pc.sig[k] = ws.col_cos(13 + k); pc.w0[k] = wires[k]; pc.w[k] = ws.col_cos(k); }
   ProfScope ps(ctx, s, "perm_constraint_coset_kernel", 320.0 * (double)ws.N, 9.0 * (double)ws.N);
   hipLaunchKernelGGL(perm_constraint_coset_kernel, dim3((unsigned)((ws.N + EW_THREADS - 1) / EW_THREADS)), dim3(EW_THREADS), 0, s, pc,
-                     (uint64_t)ws.n, fg, fe_mul(fb, fe_r2()), (uint64_t)(z_shift % ws.N), perm_out);
+                     (uint64_t)ws.n, (uint64_t)ws.plane(), fg, fe_mul(fb, fe_r2()), (uint64_t)(z_shift % ws.N), perm_out);
   HIP_TRY(ctx, hipGetLastError());
   return PLK_OK;
 }

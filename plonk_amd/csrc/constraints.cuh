@@ -69,21 +69,22 @@ __global__ __launch_bounds__(EW_THREADS) void gate_constraint_kernel(GateCols co
 
 // The same sums for a 4n-point domain held coset-major: plane r (r = 0..3) of a column holds its
 // values at the points omega_4n^(4k + r), k < n.  Plane 0 is the trace-domain column itself (the
-// table the polynomial was interpolated from), planes 1..3 are consecutive n-element blocks.
+// table the polynomial was interpolated from), planes 1..3 lie `plane` 64-bit words apart (n elements and the
+// workspace's skew, PLANE_SKEW_WORDS).
 // Thread k evaluates points 4k..4k+3 and writes them as one 128-byte run in natural order.
 struct GateColsCoset {
   const uint64_t* w0[4];  const uint64_t* s0[9];   // plane 0
-  const uint64_t* w[4];   const uint64_t* s[9];    // planes 1..3 at + (r - 1) * n elements
+  const uint64_t* w[4];   const uint64_t* s[9];    // planes 1..3 at + (r - 1) * plane words
 };
 
 // One thread per point i = 4k + r: lanes 4j..4j+3 share k and differ in the plane, so every plane
 // is read in runs of 16 consecutive elements per wave and the output store is fully coalesced.
-__global__ __launch_bounds__(EW_THREADS) void gate_constraint_coset_kernel(GateColsCoset cols, uint64_t n, uint64_t* out) {
+__global__ __launch_bounds__(EW_THREADS) void gate_constraint_coset_kernel(GateColsCoset cols, uint64_t n, uint64_t plane, uint64_t* out) {
   const uint64_t i = (uint64_t)blockIdx.x * EW_THREADS + threadIdx.x;
   if (i >= 4 * n) return;
   const uint64_t k = i >> 2;
   const int r = (int)(i & 3);
-  const uint64_t off = r ? (uint64_t)(r - 1) * n * 4 : 0;
+  const uint64_t off = r ? (uint64_t)(r - 1) * plane : 0;
   const uint64_t* s[9];
 #pragma unroll
   for (int j = 0; j < 9; ++j) s[j] = r ? (cols.s[j] ? cols.s[j] + off : nullptr) : cols.s0[j];
@@ -133,7 +134,7 @@ struct PermColsCoset {
   const uint64_t* z;   const uint64_t* sig[4];   const uint64_t* w[4];    // planes 1..3
 };
 
-__global__ __launch_bounds__(EW_THREADS) void perm_constraint_coset_kernel(PermColsCoset cols, uint64_t n, Fe gamma, Fe beta_r2,
+__global__ __launch_bounds__(EW_THREADS) void perm_constraint_coset_kernel(PermColsCoset cols, uint64_t n, uint64_t plane, Fe gamma, Fe beta_r2,
                                                                            uint64_t z_shift, uint64_t* out) {
   const uint64_t i = (uint64_t)blockIdx.x * EW_THREADS + threadIdx.x;
   const uint64_t N = 4 * n;
@@ -143,14 +144,14 @@ __global__ __launch_bounds__(EW_THREADS) void perm_constraint_coset_kernel(PermC
   uint64_t inext = i + z_shift;
   if (inext >= N) inext -= N;
   const uint64_t rn = inext & 3, kn = inext >> 2;
-  const uint64_t off = r ? (uint64_t)(r - 1) * n * 4 : 0;
+  const uint64_t off = r ? (uint64_t)(r - 1) * plane : 0;
   PermPoint pt(i, beta_r2, gamma);
   auto wire = [&](int j) {          // called four times in so many words: the loop form is not unrolled (the products hold asm statements)
     pt.wire_scaled(j, f9_load(r ? cols.w[j] + off : cols.w0[j], k), f9_load(r ? cols.sig[j] + off : cols.sig0[j], k));
   };
   wire(0); wire(1); wire(2); wire(3);
   // (z is read last: fewer values are alive across the products above)
-  fe_store(out, i, pt.finish(f9_load(rn ? cols.z + (rn - 1) * n * 4 : cols.z0, kn), f9_load(r ? cols.z + off : cols.z0, k)));
+  fe_store(out, i, pt.finish(f9_load(rn ? cols.z + (rn - 1) * plane : cols.z0, kn), f9_load(r ? cols.z + off : cols.z0, k)));
 }
 
 struct PermCols {
@@ -179,12 +180,13 @@ __global__ __launch_bounds__(EW_THREADS) void perm_constraint_kernel(PermCols co
 
 // Natural-order evaluations on the 4n-point domain from the four coset tables of a column:
 // out[4k + r] = plane_r[k].  Plane 0 is the column's own table (field elements, or raw u64 indices
-// converted with F::from), planes 1..3 are consecutive n-element blocks at `planes`.
+// converted with F::from), planes 1..3 are blocks `plane` 64-bit words apart at `planes`.
 struct Interleave4Args {
   const uint64_t* plane0[24];
   uint32_t raw_index[24];      // 1 = plane 0 holds uint64_t indices
   uint64_t* out[24];
-  const uint64_t* planes;      // column b: planes + b * 3n elements
+  const uint64_t* planes;      // column b: planes + b * 3 * plane words
+  uint64_t plane;              // 64-bit words between consecutive planes
   // Output layout: point i lands in chunk i / chunk at offset i % chunk; consecutive chunks of one
   // column are chunk_stride elements apart, and each chunk is followed by copies of the first
   // `halo` points of the next chunk (cyclically).  chunk = 4n, halo = 0 is the plain vector.
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(EW_THREADS) void interleave4_kernel(Interleave4Args
   const uint64_t k = i >> 2;
   const int r = (int)(i & 3);
   Fe v;
-  if (r) v = fe_load(a.planes + ((uint64_t)b * 3 + (r - 1)) * n * 4, k);
+  if (r) v = fe_load(a.planes + ((uint64_t)b * 3 + (r - 1)) * a.plane, k);
   else v = a.raw_index[b] ? fe_from_u64(a.plane0[b][k]) : fe_load(a.plane0[b], k);
   const uint64_t c = i / a.chunk, j = i - c * a.chunk;
   fe_store(a.out[b], c * a.chunk_stride + j, v);

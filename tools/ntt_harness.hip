@@ -33,12 +33,16 @@ int main(int argc, char** argv) {
   // twiddle records: nine 29-bit limbs (top limb small), three words of padding
   if (fill(master, 1024 * TW_WORDS * 4, 0x0fffffff, 1) || fill(master_sh, 2048 * TW_WORDS * 4, 0x0fffffff, 2) || fill(full, N * TW_WORDS * 4, 0x0fffffff, 3) ||
       fill(prescale, 3 * N * TW_WORDS * 4, 0x0fffffff, 4)) return 1;
+  // argv[2]: bytes (a multiple of 128) by which consecutive columns and consecutive slots of the intermediate buffer are
+  // skewed against each other, to see what equal offsets in equally aligned buffers cost in the caches
+  const size_t pad = argc > 2 ? (size_t)atol(argv[2]) : 0;
   std::vector<uint64_t*> in(cols), out(cols);
   for (int b = 0; b < cols; ++b) {
-    CHECK(hipMalloc(&in[b], N * 32)); CHECK(hipMalloc(&out[b], 3 * N * 32));
+    char* raw; CHECK(hipMalloc(&raw, N * 32 + cols * pad)); in[b] = (uint64_t*)(raw + b * pad);
+    CHECK(hipMalloc(&out[b], 3 * N * 32));
     if (fill(in[b], N * 32, 0x3fffffff, 10 + b)) return 1;        // below 2^254 < p: canonical elements
   }
-  uint64_t* tmp; CHECK(hipMalloc(&tmp, (size_t)slots * N * 32));
+  uint64_t* tmp; CHECK(hipMalloc(&tmp, (size_t)slots * (N * 32 + pad)));
   CHECK(hipFuncSetAttribute((const void*)ntt_pass_kernel<true, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES));
   CHECK(hipFuncSetAttribute((const void*)ntt_final_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES));
 
@@ -47,13 +51,13 @@ int main(int argc, char** argv) {
   a.n_in = N; a.log_n = log_n; a.log_r = 10; a.log_inner = 10; a.log_c = 1; a.first = 1; a.use_scaled = 1; a.pass = 0; a.cosets = cosets; a.prescale = prescale;
   a.slots = (uint32_t)slots; a.log_group = 1;
   for (int b = 0; b < cols; ++b) { a.batch.in[b] = in[b]; a.batch.kind[b] = NTT_IN_FIELD; }
-  a.batch.out[0] = tmp; a.batch.stride_out = N * 4; a.batch.stride_in = 0;
+  a.batch.out[0] = tmp; a.batch.stride_out = N * 4 + pad / 8; a.batch.stride_in = 0;
   const unsigned tiles = 1u << (log_n - 10 - 1);
 
   NttFinalArgs f{};
   f.tab = a.tab; f.n_in = N; f.log_n = log_n; f.log_r = 10; f.log_r1 = 10; f.log_r2 = 0; f.log_c = 1; f.first = 0; f.cosets = cosets; f.prescale = prescale;
   f.coset_stride = N * 4;
-  f.batch.in[0] = tmp; f.batch.stride_in = N * 4; f.batch.kind[0] = NTT_IN_FIELD;
+  f.batch.in[0] = tmp; f.batch.stride_in = N * 4 + pad / 8; f.batch.kind[0] = NTT_IN_FIELD;
   for (int b = 0; b < cols; ++b) f.batch.out[b] = out[b];
   f.batch.stride_out = 0;
 
