@@ -90,3 +90,29 @@ def test_field_instantiations_share_no_symbols_of_their_own():
                "DW.ref.__gxx_personality_v0", "__clang_call_terminate", "decltype", "auto std::", "unsigned long std::", "int std::")
     own = [n for n in names if not n.startswith(allowed)]
     assert own == [], own
+
+
+def test_header_is_plain_c():
+    """The boundary is a C ABI: the header must compile as C99 on its own (no C++ in it), and a C program that
+    names every declared entry point must link against the library."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no C compiler")
+    header = os.path.join(ROOT, "include", "plonk_hip.h")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wpedantic", "-Werror", "-fsyntax-only", "-x", "c", header], check=True)
+    names = sorted(set(re.findall(r"\b(plk_[a-z0-9_]+)\s*\(", open(header).read())))
+    src = '#include "plonk_hip.h"\n#include <stdio.h>\nint main(void) {\n  const void* fns[] = {' + ", ".join(f"(const void*){n}" for n in names) + \
+          '};\n  printf("%d\\n", (int)(sizeof fns / sizeof fns[0]));\n  return 0;\n}\n'
+    lib_dir = os.path.join(ROOT, "plonk_amd")
+    if not os.path.exists(os.path.join(lib_dir, "libplonk_hip.so")):
+        pytest.skip("library not built")
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "link_all.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "link_all")
+        subprocess.run(["gcc", "-std=c99", "-Wall", "-Wno-pedantic", "-I", os.path.join(ROOT, "include"), c, "-o", exe, "-L", lib_dir, "-lplonk_hip",
+                        f"-Wl,-rpath,{lib_dir}", "-Wl,--unresolved-symbols=ignore-in-shared-libs"], check=True)
+        out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout
+        assert int(out) == len(names) and len(names) >= 60
