@@ -1027,6 +1027,27 @@ int r23_perm(plk_ctx* ctx, hipStream_t s, const R23Ws& ws, const uint64_t* const
   return PLK_OK;
 }
 
+// both vectors from one pass over the planes (PLK_FUSED_CONSTRAINTS=0 keeps the two kernels)
+#ifndef PLK_FUSED_CONSTRAINTS
+#define PLK_FUSED_CONSTRAINTS 1
+#endif
+int r23_gate_and_perm(plk_ctx* ctx, hipStream_t s, const R23Ws& ws, const uint64_t* const wires[4], const uint64_t* const sel[9],
+                      const uint64_t beta[4], const uint64_t gamma[4], size_t z_shift, uint64_t* gate_out, uint64_t* perm_out) {
+  const Fe fb = fe_from_limbs64(beta), fg = fe_from_limbs64(gamma);
+  GateColsCoset g{};
+  PermColsCoset pc{};
+  int ncols = 5 + 10;       // wires, gate vector; sigma, Z twice, permutation vector
+  for (int k = 0; k < 4; ++k) { g.w0[k] = wires[k]; g.w[k] = ws.col_cos(k); pc.w0[k] = wires[k]; pc.w[k] = ws.col_cos(k); }
+  for (int k = 0; k < 9; ++k) { const bool on = sel && sel[k]; g.s0[k] = on ? sel[k] : nullptr; g.s[k] = on ? ws.col_cos(4 + k) : nullptr; ncols += on; }
+  pc.z0 = ws.z; pc.z = ws.col_cos(17);
+  for (int k = 0; k < 4; ++k) { pc.sig0[k] = ws.sigma_plane0(k); pc.sig[k] = ws.col_cos(13 + k); }
+  ProfScope ps(ctx, s, "round23_constraints_coset_kernel", 32.0 * ncols * (double)ws.N, 16.0 * (double)ws.N);
+  hipLaunchKernelGGL(round23_constraints_coset_kernel, dim3((unsigned)((ws.N + EW_THREADS - 1) / EW_THREADS)), dim3(EW_THREADS), 0, s, g, pc,
+                     (uint64_t)ws.n, (uint64_t)ws.plane(), fg, fe_mul(fb, fe_r2()), (uint64_t)(z_shift % ws.N), gate_out, perm_out);
+  HIP_TRY(ctx, hipGetLastError());
+  return PLK_OK;
+}
+
 bool r23_coset_form(size_t n, size_t N, int log_n) { return N == 4 * n && log_n >= 2 && log_n + 2 <= Field::TWO_ADICITY; }
 
 // Makes `s` wait for the side stream before the enclosing function returns, whatever happens in between.
@@ -1069,6 +1090,10 @@ int launch_round23(plk_ctx* ctx, hipStream_t s, const uint64_t* const wires[4], 
     const SigmaScale sg_scale(ws, beta, (int)m);
     for (int k = 0; k < 4; ++k) { in[m] = sigma[k]; kinds[m] = NTT_IN_U64; col_of[m] = 13 + k; ++m; }
     if ((rc = r23_extend_group(ctx, s, ws, in, kinds, col_of, m, "ntt_tmp", &sg_scale.opt))) return rc;
+    if (PLK_FUSED_CONSTRAINTS && gate_out && perm_out) {
+      side.join();
+      return r23_gate_and_perm(ctx, s, ws, wires, sel, beta, gamma, z_shift, gate_out, perm_out);
+    }
     if (gate_out && (rc = r23_gate(ctx, s, ws, wires, sel, gate_out))) return rc;
     side.join();
     if (perm_out && (rc = r23_perm(ctx, s, ws, wires, sigma, beta, gamma, z_shift, perm_out))) return rc;

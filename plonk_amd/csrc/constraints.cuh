@@ -154,6 +154,36 @@ __global__ __launch_bounds__(EW_THREADS) void perm_constraint_coset_kernel(PermC
   fe_store(out, i, pt.finish(f9_load(rn ? cols.z + (rn - 1) * plane : cols.z0, kn), f9_load(r ? cols.z + off : cols.z0, k)));
 }
 
+// Both constraint vectors in one pass: the wire planes (a quarter of what the two kernels above read between them)
+// are loaded once and serve the gate sum and the permutation products of the point.
+#ifndef PLK_FUSED_CONSTRAINTS_WAVES
+#define PLK_FUSED_CONSTRAINTS_WAVES 1
+#endif
+__global__ __launch_bounds__(EW_THREADS, PLK_FUSED_CONSTRAINTS_WAVES) void round23_constraints_coset_kernel(
+    GateColsCoset gc, PermColsCoset pc, uint64_t n, uint64_t plane, Fe gamma, Fe beta_r2, uint64_t z_shift, uint64_t* gate_out, uint64_t* perm_out) {
+  const uint64_t i = (uint64_t)blockIdx.x * EW_THREADS + threadIdx.x;
+  const uint64_t N = 4 * n;
+  if (i >= N) return;
+  const uint64_t k = i >> 2;
+  const int r = (int)(i & 3);
+  const uint64_t off = r ? (uint64_t)(r - 1) * plane : 0;
+  const uint64_t* s[9];
+#pragma unroll
+  for (int j = 0; j < 9; ++j) s[j] = r ? (gc.s[j] ? gc.s[j] + off : nullptr) : gc.s0[j];
+  const F9 a = f9_load(r ? gc.w[0] + off : gc.w0[0], k), b = f9_load(r ? gc.w[1] + off : gc.w0[1], k);
+  const F9 c = f9_load(r ? gc.w[2] + off : gc.w0[2], k), o = f9_load(r ? gc.w[3] + off : gc.w0[3], k);
+  fe_store(gate_out, i, gate_point(a, b, c, o, s, k));
+  uint64_t inext = i + z_shift;
+  if (inext >= N) inext -= N;
+  const uint64_t rn = inext & 3, kn = inext >> 2;
+  PermPoint pt(i, beta_r2, gamma);
+  pt.wire_scaled(0, a, f9_load(r ? pc.sig[0] + off : pc.sig0[0], k));
+  pt.wire_scaled(1, b, f9_load(r ? pc.sig[1] + off : pc.sig0[1], k));
+  pt.wire_scaled(2, c, f9_load(r ? pc.sig[2] + off : pc.sig0[2], k));
+  pt.wire_scaled(3, o, f9_load(r ? pc.sig[3] + off : pc.sig0[3], k));
+  fe_store(perm_out, i, pt.finish(f9_load(rn ? pc.z + (rn - 1) * plane : pc.z0, kn), f9_load(r ? pc.z + off : pc.z0, k)));
+}
+
 struct PermCols {
   const uint64_t* z;
   const uint64_t* s[4];

@@ -37,6 +37,7 @@ BY_GRID = {
                          ["ntt_final_kernel/intt20"], ["ntt_final_kernel/lde20to22"]],
     "gate_constraint_coset_kernel": [["gate_constraint_coset_kernel"]],
     "perm_constraint_coset_kernel": [["perm_constraint_coset_kernel"]],
+    "round23_constraints_coset_kernel": [["round23_constraints_coset_kernel"]],
 }
 STEP = [l for groups in BY_GRID.values() for g in groups for l in g]
 
