@@ -159,6 +159,28 @@ def test_node_round23_batch(prover):
         node.close()
 
 
+def test_node_round23_fewest_rows_and_columns():
+    """Four rows over four ranks (one point of the trace domain each, the halo as long as the range), and eight ranks
+    with nine columns to deal (no selectors: most ranks hold one column and an unused slot)."""
+    from plonk_amd.device import DeviceProver
+    prover = DeviceProver(0)
+    for G, n, kinds, z_shift in ((4, 4, None, 4), (4, 4, (), 1), (8, 64, (), 4), (8, 8, ("Add",), 3)):
+        from plonk_amd.api import AST_KINDS
+        N = 4 * n
+        node = Node([0] * G, exchange="copy")
+        try:
+            c = synth.make_circuit(n, circuit_id=77 + G + n, kinds=AST_KINDS if kinds is None else kinds)
+            copies = [prover.upload(c) for _ in range(G)]
+            outs = [(prover.empty(n + 1), prover.empty(N // G), prover.empty(N // G)) for _ in range(G)]
+            node.round23(copies, N, outs, z_shift=z_shift)
+            zr, gr, er = co.round23(c.table.wires(), c.table.selectors, c.perm.columns(), N, c.beta, c.gamma, z_shift=z_shift)
+            assert all(np.array_equal(to_host(o[0]), zr) for o in outs)
+            assert np.array_equal(np.concatenate([to_host(o[1]) for o in outs]), gr), (G, n, kinds)
+            assert np.array_equal(np.concatenate([to_host(o[2]) for o in outs]), er), (G, n, kinds)
+        finally:
+            node.close()
+
+
 @pytest.mark.parametrize("G,kinds", [(1, None), (2, None), (4, ("Add", "Mul", "Const")), (8, None), (2, ())])
 def test_node_round23_one_proof_over_the_ranks(prover, G, kinds):
     """plk_node_round23: the columns dealt to G ranks, one exchange, the constraints on N / G points per rank - the
