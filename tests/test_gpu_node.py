@@ -159,6 +159,22 @@ def test_node_round23_batch(prover):
         node.close()
 
 
+def test_node_round23_rccl_one_rank(prover):
+    """The one-proof mode with RCCL's all-to-all as its exchange, in the one-rank node a single GPU allows."""
+    n, N = 1 << 12, 1 << 14
+    node = Node([0], exchange="rccl")
+    try:
+        c = synth.make_circuit(n, circuit_id=401)
+        dc = prover.upload(c)
+        outs = [(prover.empty(n + 1), prover.empty(N), prover.empty(N))]
+        for z_shift in (1, 4):
+            node.round23([dc], N, outs, z_shift=z_shift)
+            zr, gr, er = co.round23(c.table.wires(), c.table.selectors, c.perm.columns(), N, c.beta, c.gamma, z_shift=z_shift)
+            assert np.array_equal(to_host(outs[0][0]), zr) and np.array_equal(to_host(outs[0][1]), gr) and np.array_equal(to_host(outs[0][2]), er)
+    finally:
+        node.close()
+
+
 def test_node_round23_fewest_rows_and_columns():
     """Four rows over four ranks (one point of the trace domain each, the halo as long as the range), and eight ranks
     with nine columns to deal (no selectors: most ranks hold one column and an unused slot)."""
