@@ -484,7 +484,9 @@ int plk_node_round23_batch(plk_node* node, const plk_circuit_io* circuits, size_
  * columns, all points" into "all columns, my points" (with a z_shift-point halo of Z), and every rank evaluates both
  * constraint vectors on its range: per_rank[g].z_out receives the whole Z (n + 1 elements, computed on every rank),
  * gate_out / perm_out the points [g N / G, (g + 1) N / G) of the vectors plk_round23 returns (N / G elements each).
- * Returns when every rank is done; data-dependent failures come back as for plk_round23. */
+ * Returns when every rank is done; data-dependent failures come back as for plk_round23 with the rank named in
+ * plk_node_last_error.  Every rank keeps two exchange buffers of G * ceil(18 / G) * (N / G + z_shift) elements
+ * (grow-only, released by plk_node_destroy) beside its context's workspace: 2 x 403 MB at n = 2^20, G = 8. */
 int plk_node_round23(plk_node* node, const plk_circuit_io* per_rank, size_t n, size_t N, size_t z_shift);
 
 #ifdef __cplusplus
