@@ -116,3 +116,14 @@ def test_header_is_plain_c():
                         f"-Wl,-rpath,{lib_dir}", "-Wl,--unresolved-symbols=ignore-in-shared-libs"], check=True)
         out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout
         assert int(out) == len(names) and len(names) >= 60
+
+
+def test_generated_dispatch_is_up_to_date(tmp_path, capsys):
+    """field_syms.h and dispatch.cpp are generated from the header: what is committed is what the generator writes now."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_field_dispatch", os.path.join(ROOT, "tools", "gen_field_dispatch.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    gen.main(str(tmp_path))
+    for name in ("field_syms.h", "dispatch.cpp"):
+        assert open(tmp_path / name).read() == open(os.path.join(ROOT, "plonk_amd", "csrc", name)).read(), name
