@@ -489,6 +489,13 @@ int plk_node_round23_batch(plk_node* node, const plk_circuit_io* circuits, size_
  * (grow-only, released by plk_node_destroy) beside its context's workspace: 2 x 403 MB at n = 2^20, G = 8. */
 int plk_node_round23(plk_node* node, const plk_circuit_io* per_rank, size_t n, size_t N, size_t z_shift);
 
+/* plk_node_round23 on HOST arrays, the arguments of plk_round23: every rank's GPU receives the columns over its own
+ * link, the ranks' pieces of the two constraint vectors come back into gate_out / perm_out (N elements each), Z from
+ * rank 0 into z_out (n + 1).  N = 4 n only.  The columns stay in a per-rank buffer the node keeps (grow-only). */
+int plk_node_round23_host(plk_node* node, const uint64_t* const wires[4], const uint64_t* const sel[PLK_NUM_SELECTORS],
+                          const uint64_t* const sigma[4], size_t n, size_t N, const uint64_t beta[4], const uint64_t gamma[4],
+                          size_t z_shift, uint64_t* z_out, uint64_t* gate_out, uint64_t* perm_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -500,55 +500,30 @@ inline std::vector<Fr> evaluate_over_domain(const DensePolynomial& p, const Gene
   return evals;
 }
 
-// prove_round23 with the ONE circuit's columns dealt to the node's ranks (plk_node_round23): host vectors in and out.
-// Every rank's GPU receives the columns, rank g returns the points [g N / G, (g + 1) N / G) of both constraint vectors.
+// prove_round23 with the ONE circuit's columns dealt to the node's ranks (plk_node_round23_host): host vectors in and
+// out.  Every rank's GPU receives the columns, rank g computes the points [g N / G, (g + 1) N / G) of both vectors.
 inline Round23 prove_round23(const GateEvaluationTable& table, const PermutationTable& perm, const Fr& beta, const Fr& gamma,
                              const GeneralEvaluationDomain& n_domain, const GeneralEvaluationDomain& evaluation_domain, size_t z_shift, Node& node) {
-  const size_t n = n_domain.size(), N = evaluation_domain.size(), G = node.ranks(), piece = N / G, fe = sizeof(Fr);
+  const size_t n = n_domain.size(), N = evaluation_domain.size();
   const std::vector<Fr>* w[4] = {&table.input1, &table.input2, &table.input3, &table.output};
   const std::vector<uint64_t>* sg[4] = {&perm.sigma1, &perm.sigma2, &perm.sigma3, &perm.sigma_output};
-  for (int k = 0; k < 4; ++k)
+  const uint64_t *wires[4], *sigma[4];
+  const uint64_t* sel[PLK_NUM_SELECTORS] = {nullptr};
+  for (int k = 0; k < 4; ++k) {
     if (w[k]->size() != n || sg[k]->size() != n) throw LengthMismatch(PLK_ERR_LENGTH, plk_strerror(PLK_ERR_LENGTH));
-  for (const auto& kv : table.selectors)
-    if (kv.second.size() != n) throw LengthMismatch(PLK_ERR_LENGTH, plk_strerror(PLK_ERR_LENGTH));
-  struct Held {                      // device allocations of one call, released whatever happens
-    std::vector<std::pair<plk_ctx*, void*>> v;
-    ~Held() { for (auto& e : v) plk_dev_free(e.first, e.second); }
-  } held;
-  auto check_ctx = [](plk_ctx* c, int rc) { if (rc != PLK_OK) throw Error(rc, plk_last_error(c)); };
-  auto put = [&](plk_ctx* c, const void* src, size_t bytes) {
-    void* d = nullptr;
-    check_ctx(c, plk_dev_alloc(c, bytes, &d));
-    held.v.emplace_back(c, d);
-    if (src) check_ctx(c, plk_dev_upload(c, plk_ctx_stream(c), d, src, bytes));
-    return (uint64_t*)d;
-  };
-  std::vector<plk_circuit_io> io(G);
-  for (size_t g = 0; g < G; ++g) {
-    plk_ctx* c = plk_node_ctx(node.get(), g);
-    plk_circuit_io& o = io[g];
-    for (int k = 0; k < 4; ++k) {
-      o.wires[k] = put(c, detail::ptr(*w[k]), n * fe);
-      o.sigma[k] = put(c, sg[k]->data(), n * sizeof(uint64_t));
-    }
-    for (int k = 0; k < PLK_NUM_SELECTORS; ++k) o.sel[k] = nullptr;
-    for (const auto& kv : table.selectors) o.sel[(int)kv.first] = put(c, detail::ptr(kv.second), n * fe);
-    for (int k = 0; k < 4; ++k) { o.beta[k] = beta[k]; o.gamma[k] = gamma[k]; }
-    o.z_out = put(c, nullptr, (n + 1) * fe);
-    o.gate_out = put(c, nullptr, piece * fe);
-    o.perm_out = put(c, nullptr, piece * fe);
+    wires[k] = detail::ptr(*w[k]);
+    sigma[k] = sg[k]->data();
   }
-  node.check(plk_node_round23(node.get(), io.data(), n, N, z_shift));
+  for (const auto& kv : table.selectors) {
+    if (kv.second.size() != n) throw LengthMismatch(PLK_ERR_LENGTH, plk_strerror(PLK_ERR_LENGTH));
+    sel[(int)kv.first] = detail::ptr(kv.second);
+  }
   Round23 r;
   r.z.resize(n + 1);
   r.gate_constraints.resize(N);
   r.permutation_constraints.resize(N);
-  check_ctx(plk_node_ctx(node.get(), 0), plk_dev_download(plk_node_ctx(node.get(), 0), plk_ctx_stream(plk_node_ctx(node.get(), 0)), detail::ptr(r.z), io[0].z_out, (n + 1) * fe));
-  for (size_t g = 0; g < G; ++g) {
-    plk_ctx* c = plk_node_ctx(node.get(), g);
-    check_ctx(c, plk_dev_download(c, plk_ctx_stream(c), r.gate_constraints[g * piece].data(), io[g].gate_out, piece * fe));
-    check_ctx(c, plk_dev_download(c, plk_ctx_stream(c), r.permutation_constraints[g * piece].data(), io[g].perm_out, piece * fe));
-  }
+  node.check(plk_node_round23_host(node.get(), wires, sel, sigma, n, N, beta.data(), gamma.data(), z_shift, detail::ptr(r.z),
+                                   detail::ptr(r.gate_constraints), detail::ptr(r.permutation_constraints)));
   return r;
 }
 

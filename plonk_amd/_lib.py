@@ -128,6 +128,7 @@ SIGNATURES = {
     "plk_node_sync": (C.c_int, [C.c_void_p]),
     "plk_node_round23_batch": (C.c_int, [C.c_void_p, C.POINTER(CircuitIO), C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t]),
     "plk_node_round23": (C.c_int, [C.c_void_p, C.POINTER(CircuitIO), C.c_size_t, C.c_size_t, C.c_size_t]),
+    "plk_node_round23_host": (C.c_int, [C.c_void_p, u64pp, u64pp, u64pp, C.c_size_t, C.c_size_t, u64p, u64p, C.c_size_t, u64p, u64p, u64p]),
     "plk_dev_to_montgomery": (C.c_int, [C.c_void_p, C.c_void_p, u64p, C.c_size_t, u64p]),
     "plk_dev_from_montgomery": (C.c_int, [C.c_void_p, C.c_void_p, u64p, C.c_size_t, u64p]),
 }

@@ -135,9 +135,10 @@ struct Rank {
   hipStream_t stream = nullptr;           // the context's own stream
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};   // "my blocks of exchange k have been pushed"
   hipEvent_t done = nullptr;              // "my part of the last call has finished and my output is complete"
-  // A, B, C; D, E = shards of plk_node_ntt_host; F, G = send and receive buffers of plk_node_round23
-  void* buf[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  size_t cap[7] = {0, 0, 0, 0, 0, 0, 0};
+  // A, B, C; D, E = shards of plk_node_ntt_host; F, G = send and receive buffers of plk_node_round23; H = the columns
+  // and outputs of plk_node_round23_host
+  void* buf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   ncclComm_t comm = nullptr;
   int rc = PLK_OK;
   std::string err;
@@ -557,6 +558,60 @@ int plk_node_round23(plk_node* node, const plk_circuit_io* per_rank, size_t n, s
   });
   node->have_done = true;
   return collect(node, "plk_node_round23");
+}
+
+// plk_node_round23 on host arrays: the columns go up to every rank's GPU (each over its own link), the pieces of the
+// two constraint vectors come down from the rank that computed them, Z from rank 0.
+int plk_node_round23_host(plk_node* node, const uint64_t* const wires[4], const uint64_t* const sel[9], const uint64_t* const sigma[4],
+                          size_t n, size_t N, const uint64_t beta[4], const uint64_t gamma[4], size_t z_shift, uint64_t* z_out,
+                          uint64_t* gate_out, uint64_t* perm_out) {
+  if (!node) return PLK_ERR_ARG;
+  node->last_error.clear();
+  if (!wires || !sigma || !beta || !gamma || !z_out || !gate_out || !perm_out) return node_fail(node, PLK_ERR_ARG, "null pointer");
+  for (int k = 0; k < 4; ++k) if (!wires[k] || !sigma[k]) return node_fail(node, PLK_ERR_ARG, "null column pointer");
+  const size_t G = node->r.size();
+  if (log2_exact(n) < 2 || N != 4 * n || N % G) return node_fail(node, PLK_ERR_ARG, "plk_node_round23_host takes N = 4 n, n a power of two >= 4, and ranks that divide N");
+  const size_t piece = N / G, col = n * ELEM, idx = n * sizeof(uint64_t);
+  // the slab of one rank: 4 wires, 9 selectors, 4 sigma (u64), Z (n + 1), the two pieces; every part at a multiple of 256 bytes
+  auto up = [](size_t b) { return (b + 255) & ~size_t(255); };
+  const size_t o_w = 0, o_s = o_w + 4 * up(col), o_g = o_s + 9 * up(col), o_z = o_g + 4 * up(idx), o_gate = o_z + up(col + ELEM),
+               o_perm = o_gate + up(piece * ELEM), total = o_perm + up(piece * ELEM);
+  int rc = ensure_buffers(node, 7, 7, total);
+  if (rc) return rc;
+  std::vector<plk_circuit_io> io(G);
+  node->workers.run([&](size_t g) {
+    Rank& me = node->r[g];
+    me.rc = PLK_OK; me.err.clear();
+    if (!HIP_OK(hipSetDevice(me.device))) return;
+    char* base = (char*)me.buf[7];
+    plk_circuit_io& c = io[g];
+    bool ok = true;
+    for (int k = 0; k < 4 && ok; ++k) {
+      c.wires[k] = (const uint64_t*)(base + o_w + k * up(col));
+      c.sigma[k] = (const uint64_t*)(base + o_g + k * up(idx));
+      ok = PLK_OKAY(plk_dev_upload(me.ctx, me.stream, (void*)c.wires[k], wires[k], col)) &&
+           PLK_OKAY(plk_dev_upload(me.ctx, me.stream, (void*)c.sigma[k], sigma[k], idx));
+    }
+    for (int k = 0; k < 9 && ok; ++k) {
+      c.sel[k] = nullptr;
+      if (!sel || !sel[k]) continue;
+      c.sel[k] = (const uint64_t*)(base + o_s + k * up(col));
+      ok = PLK_OKAY(plk_dev_upload(me.ctx, me.stream, (void*)c.sel[k], sel[k], col));
+    }
+    for (int k = 0; k < 4; ++k) { c.beta[k] = beta[k]; c.gamma[k] = gamma[k]; }
+    c.z_out = (uint64_t*)(base + o_z); c.gate_out = (uint64_t*)(base + o_gate); c.perm_out = (uint64_t*)(base + o_perm);
+  });
+  if ((rc = collect(node, "plk_node_round23_host (upload)"))) return rc;
+  if ((rc = plk_node_round23(node, io.data(), n, N, z_shift))) return rc;
+  node->workers.run([&](size_t g) {
+    Rank& me = node->r[g];
+    me.rc = PLK_OK; me.err.clear();
+    if (!HIP_OK(hipSetDevice(me.device))) return;
+    bool ok = PLK_OKAY(plk_dev_download(me.ctx, me.stream, (char*)gate_out + g * piece * ELEM, io[g].gate_out, piece * ELEM)) &&
+              PLK_OKAY(plk_dev_download(me.ctx, me.stream, (char*)perm_out + g * piece * ELEM, io[g].perm_out, piece * ELEM));
+    if (ok && g == 0) (void)PLK_OKAY(plk_dev_download(me.ctx, me.stream, z_out, io[0].z_out, (n + 1) * ELEM));
+  });
+  return collect(node, "plk_node_round23_host (download)");
 }
 
 }  // extern "C"

@@ -104,3 +104,31 @@ class Node:
         arr = self._io(copies, outs)
         self.check(self.lib.plk_node_round23(self.handle, arr, copies[0].n, N, z_shift))
         return outs
+
+    def round23_host(self, circuit, N: int, z_shift: int = 1):
+        """Rounds 2+3 of one circuit given as host arrays (`plonk_amd.synth.Circuit`), over the node's ranks: returns
+        (z, gate, perm) as host arrays, the shapes `plonk_amd.api.prove_round23` returns."""
+        n = circuit.n
+        keep = []
+
+        def table(arrays):
+            arr = (C.c_void_p * len(arrays))()
+            for i, a in enumerate(arrays):
+                if a is None:
+                    arr[i] = None
+                    continue
+                a = np.ascontiguousarray(a, dtype=np.uint64)
+                keep.append(a)
+                arr[i] = a.ctypes.data
+            return C.cast(arr, _lib.u64pp)
+
+        beta = np.ascontiguousarray(circuit.beta, dtype=np.uint64).reshape(4)
+        gamma = np.ascontiguousarray(circuit.gamma, dtype=np.uint64).reshape(4)
+        z = np.empty((n + 1, 4), dtype=np.uint64)
+        gate = np.empty((N, 4), dtype=np.uint64)
+        perm = np.empty((N, 4), dtype=np.uint64)
+        self.check(self.lib.plk_node_round23_host(
+            self.handle, table(circuit.table.wires()), table([circuit.table.selectors.get(k) for k in AST_KINDS]),
+            table(circuit.perm.columns()), n, N, beta.ctypes.data_as(_lib.u64p), gamma.ctypes.data_as(_lib.u64p), z_shift,
+            z.ctypes.data_as(_lib.u64p), gate.ctypes.data_as(_lib.u64p), perm.ctypes.data_as(_lib.u64p)))
+        return z, gate, perm

@@ -128,4 +128,7 @@ extern "C" {
     pub fn plk_node_round23_batch(node: *mut plk_node, circuits: *const plk_circuit_io, count: usize, n: usize, big_n: usize,
                                   z_shift: usize) -> c_int;
     pub fn plk_node_round23(node: *mut plk_node, per_rank: *const plk_circuit_io, n: usize, big_n: usize, z_shift: usize) -> c_int;
+    pub fn plk_node_round23_host(node: *mut plk_node, wires: *const *const u64, sel: *const *const u64, sigma: *const *const u64, n: usize,
+                                 big_n: usize, beta: *const u64, gamma: *const u64, z_shift: usize, z_out: *mut u64, gate_out: *mut u64,
+                                 perm_out: *mut u64) -> c_int;
 }

@@ -513,6 +513,23 @@ pub fn prove_round23<F: FftField>(
     let mut z = vec![F::zero(); n + 1];
     let mut gate = vec![F::zero(); big_n];
     let mut perm = vec![F::zero(); big_n];
+    // on a configured node (BLS12-381 Fr, the 4n domain, circuits of at least PLONK_HIP_NODE_MIN_SIZE points): the one
+    // proof's columns are dealt to the node's GPUs
+    if field == 0 && big_n == 4 * n && n >= 4 && big_n >= node_min_size()
+        && with_node(|node| {
+            let rc = unsafe {
+                sys::plk_node_round23_host(node, wires.as_ptr(), sel.as_ptr(), sigma.as_ptr(), n, big_n, one_elem(&beta), one_elem(&gamma), 1,
+                                           limbs_mut(&mut z), limbs_mut(&mut gate), limbs_mut(&mut perm))
+            };
+            if rc == sys::PLK_OK {
+                Ok(())
+            } else {
+                Err(format!("libplonk_hip: {}", unsafe { CStr::from_ptr(sys::plk_node_last_error(node)) }.to_string_lossy()))
+            }
+        })
+    {
+        return (z, gate, perm);
+    }
     with_ctx(field, |ctx| {
         let rc = unsafe {
             sys::plk_round23(ctx, wires.as_ptr(), sel.as_ptr(), sigma.as_ptr(), n, big_n, one_elem(&beta), one_elem(&gamma), 1,

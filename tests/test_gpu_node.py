@@ -175,6 +175,24 @@ def test_node_round23_rccl_one_rank(prover):
         node.close()
 
 
+def test_node_round23_host_arrays():
+    """plk_node_round23_host: host arrays in and out over four ranks, against the CPU restatement; twice (the node keeps
+    the columns' buffers), the second circuit smaller and without some selectors; then its argument errors."""
+    node = Node([0] * 4, exchange="copy")
+    try:
+        for n, kinds, z_shift in ((1 << 12, None, 1), (1 << 8, ("Add", "Mult", "If"), 4)):
+            from plonk_amd.api import AST_KINDS
+            c = synth.make_circuit(n, circuit_id=500 + n, kinds=AST_KINDS if kinds is None else kinds)
+            z, g, e = node.round23_host(c, 4 * n, z_shift=z_shift)
+            zr, gr, er = co.round23(c.table.wires(), c.table.selectors, c.perm.columns(), 4 * n, c.beta, c.gamma, z_shift=z_shift)
+            assert np.array_equal(z, zr) and np.array_equal(g, gr) and np.array_equal(e, er)
+        with pytest.raises(pa.PlonkError) as ei:
+            node.round23_host(c, 2 * n)
+        assert ei.value.code == _lib.PLK_ERR_ARG
+    finally:
+        node.close()
+
+
 def test_node_round23_fewest_rows_and_columns():
     """Four rows over four ranks (one point of the trace domain each, the halo as long as the range), and eight ranks
     with nine columns to deal (no selectors: most ranks hold one column and an unused slot)."""
