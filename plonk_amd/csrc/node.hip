@@ -1,9 +1,15 @@
 // G ranks in ONE process, one GPU each (declared in include/plonk_hip.h: plk_node_*).
 //
 // Host code only.  Everything a rank computes goes through the library's public device entry points
-// (plk_dev_fourstep_cols / _rows, plk_dev_round23, plk_dev_status) on that rank's own context; this file adds what
-// turns G such contexts into one node: a host thread and a stream per rank, the three all-to-all exchanges of the
-// four-step transform, and the bookkeeping that lets the exchanges run with no host synchronisation in between.
+// (plk_dev_fourstep_cols / _rows, plk_dev_round23, plk_dev_grand_product, plk_dev_extend4, the two constraint
+// evaluations, plk_dev_status) on that rank's own context; this file adds what turns G such contexts into one node: a
+// host thread and a stream per rank, the three all-to-all exchanges of the four-step transform, the one exchange of
+// a proof whose columns are dealt to the ranks, and the bookkeeping that lets the exchanges run with no host
+// synchronisation in between.
+//
+// Three modes: plk_node_ntt (one transform sharded over the ranks), plk_node_round23 (one proof: columns dealt to the
+// ranks, then every rank evaluates its range of points), plk_node_round23_batch (whole proofs dealt to the ranks, no
+// exchange); the _host forms take host arrays.
 //
 // The reference has no counterpart: ark-poly's transform is one shared-memory job (src/polynomial_utils.rs:29,
 // src/execution_trace.rs:362-370) and nothing in the reference is distributed.
@@ -20,6 +26,7 @@
 //
 // Buffers of rank g (N / G elements each, grow-only): A = receive buffer of exchange 1, later the send buffer of
 // exchange 3; B = send buffer of exchange 2 (and pack / unpack area of the RCCL form); C = receive buffer of exchange 2.
+// plk_node_round23 has a send and a receive buffer of its own (F, G), the _host forms their staging buffers (D, E, H).
 // A call leaves an event `done` on every rank's stream; the next call's streams wait for all of them before they
 // touch another rank's buffers.
 #include "../../include/plonk_hip.h"
