@@ -205,6 +205,7 @@ struct plk_ctx {
   // optional per-launch timing (plk_profile_*): one event pair per kernel launch
   int two_pass_max_log = 20;                     // transforms up to 2^this take two passes, larger ones three (measured: 2^21, 2^22 are 3-8 % slower in two)
   int first_radix_log = 0;                       // measurement knob: the first radix of two-pass plans (0 = even split)
+  int fused_constraints_min_log = 16;            // rounds 2+3 of at least 2^this rows take both constraint vectors from one kernel
   bool profiling = false;
   struct ProfRec { std::string label; hipEvent_t e0, e1; double alg_bytes; double products; };
   std::vector<ProfRec> prof;
@@ -1090,7 +1091,10 @@ int launch_round23(plk_ctx* ctx, hipStream_t s, const uint64_t* const wires[4], 
     const SigmaScale sg_scale(ws, beta, (int)m);
     for (int k = 0; k < 4; ++k) { in[m] = sigma[k]; kinds[m] = NTT_IN_U64; col_of[m] = 13 + k; ++m; }
     if ((rc = r23_extend_group(ctx, s, ws, in, kinds, col_of, m, "ntt_tmp", &sg_scale.opt))) return rc;
-    if (PLK_FUSED_CONSTRAINTS && gate_out && perm_out) {
+    // (small circuits keep the two kernels: their critical path is the side stream's chain, and the gate vector is
+    // computed beside it instead of behind it - 0.203 against 0.213 ms per call at 2^12 rows, 0.304 against 0.316 at 2^15;
+    // from 2^16 rows on the one kernel wins: 0.464 against 0.469, 0.873 against 0.882 at 2^17)
+    if (PLK_FUSED_CONSTRAINTS && gate_out && perm_out && log_n >= ctx->fused_constraints_min_log) {
       side.join();
       return r23_gate_and_perm(ctx, s, ws, wires, sel, beta, gamma, z_shift, gate_out, perm_out);
     }
@@ -1873,6 +1877,7 @@ int plk_ctx_create(int device, plk_ctx** out) {
   if (ctx) ctx->field_id = PLK_FIELD_ID;
   if (!ctx) return PLK_ERR_NOMEM;
   if (const char* e = getenv("PLONK_NTT_FIRST_RADIX_LOG")) ctx->first_radix_log = atoi(e);
+  if (const char* e = getenv("PLONK_HIP_FUSED_MIN_LOG")) ctx->fused_constraints_min_log = atoi(e);
   if (const char* e = getenv("PLONK_NTT_TWO_PASS_MAX_LOG")) ctx->two_pass_max_log = std::max(12, std::min(atoi(e), 2 * NTT_TILE_LOG));   // measurement knob
   ctx->device = device;
 #define CTX_TRY(expr)                                                                           \

@@ -12,8 +12,12 @@ from plonk_amd.device import DeviceProver, to_host
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("field,seed", [(0, 11), (1, 12)])
-def test_random_circuits_match_the_oracle(field, seed):
+@pytest.mark.parametrize("field,seed,fused_from", [(0, 11, None), (1, 12, None), (0, 13, "0"), (1, 14, "0")])
+def test_random_circuits_match_the_oracle(field, seed, fused_from, monkeypatch):
+    """`fused_from` = "0": the context takes both constraint vectors from the one kernel at every size (the library
+    does so from 2^16 rows on), so that the small random cases cover that kernel as well."""
+    if fused_from is not None:
+        monkeypatch.setenv("PLONK_HIP_FUSED_MIN_LOG", fused_from)
     rng = np.random.default_rng(seed)
     prover = DeviceProver(0, field=field)
     F = synth.field(field)
