@@ -201,11 +201,7 @@ def test_pointwise_kernels_at_extreme_values(prover):
             assert got[i] == (z[(i + shift) % N] * lhs - z[i] * rhs) % p, ("perm", shift, i)
 
 
-@pytest.mark.parametrize("log_n,kinds", [(3, pa.AST_KINDS), (8, pa.AST_KINDS), (8, ("Add", "Div", "If")), (12, ("Sub", "Mult", "Eq", "Not"))])
-def test_round23_at_extreme_values(ctx, log_n, kinds):
-    """Rounds 2+3 on the 4n-point domain (the coset-major kernels: gate sum regrouped by wire, sigma columns carried
-    times beta through their transforms) with wire and selector columns made of 0, 1, 2, p - 1, p - 2, p - 3,
-    (p - 1) / 2 and random elements, selectors that are not 0/1 included, against the CPU oracle."""
+def _extreme_circuit(log_n, kinds):
     n = 1 << log_n
     p = synth.P_INT
     special = [0, 1, p - 1, p - 2, (p - 1) // 2, 2, p - 3]
@@ -223,6 +219,36 @@ def test_round23_at_extreme_values(ctx, log_n, kinds):
     for j, k in enumerate(sorted(c.table.selectors)):
         if j % 2 == 0:
             c.table.selectors[k] = column(4, j)
+    return c
+
+
+EXTREME_CASES = [(3, pa.AST_KINDS), (8, pa.AST_KINDS), (8, ("Add", "Div", "If")), (12, ("Sub", "Mult", "Eq", "Not"))]
+
+
+@pytest.mark.parametrize("log_n,kinds", EXTREME_CASES)
+def test_round23_at_extreme_values(ctx, log_n, kinds):
+    """Rounds 2+3 on the 4n-point domain (the coset-major kernels: gate sum regrouped by wire, sigma columns carried
+    times beta through their transforms) with wire and selector columns made of 0, 1, 2, p - 1, p - 2, p - 3,
+    (p - 1) / 2 and random elements, selectors that are not 0/1 included, against the CPU oracle."""
+    n = 1 << log_n
+    c = _extreme_circuit(log_n, kinds)
     z, g, e = pa.prove_round23(c.table, c.perm, c.beta, c.gamma, D(n), D(4 * n), ctx=ctx)
     zr, gr, er = co.round23(c.table.wires(), c.table.selectors, c.perm.columns(), 4 * n, c.beta, c.gamma)
     assert same(z, zr) and same(g, gr) and same(e, er)
+
+
+@pytest.mark.parametrize("log_n,kinds", EXTREME_CASES)
+def test_round23_at_extreme_values_one_kernel(monkeypatch, log_n, kinds):
+    """The same circuits through the device-resident call with both constraint vectors taken from the one kernel (what
+    the library does from 2^16 rows on, asked for here at every size), several z_shift."""
+    from plonk_amd.device import DeviceProver, to_host
+    monkeypatch.setenv("PLONK_HIP_FUSED_MIN_LOG", "0")
+    prover = DeviceProver(0)
+    n = 1 << log_n
+    c = _extreme_circuit(log_n, kinds)
+    dc = prover.upload(c)
+    for z_shift in (1, 4, 4 * n - 1):
+        z, g, e = prover.round23(dc, 4 * n, z_shift=z_shift)
+        prover.status()
+        zr, gr, er = co.round23(c.table.wires(), c.table.selectors, c.perm.columns(), 4 * n, c.beta, c.gamma, z_shift=z_shift)
+        assert np.array_equal(to_host(z), zr) and np.array_equal(to_host(g), gr) and np.array_equal(to_host(e), er), z_shift
