@@ -681,7 +681,7 @@ def main():
                        "field": ("BLS12-381 Fr", "Tweedle Fr (second instantiation: constants self-derived, not the headline field)")[args.field],
                        "circuits_per_step": world},
             "host_call_note": "inputs and outputs resident in HBM; the reference-shaped call on host vectors (plk_round23) moves 772 MB "
-                              "over PCIe per call and takes 15.7 ms page-locked / 26 ms pageable at this size (DESIGN.md section 5)",
+                              "over PCIe per call and takes 15.7 ms page-locked / 26 ms pageable at this size",
             "proofs_per_s": round(world / (ms_per_step * 1e-3), 3),
             "step_alg_bytes": alg_bytes_step,
             "step_frac_of_hbm_roofline": round(alg_bytes_step / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if alg_bytes_step else None,
